@@ -1,0 +1,141 @@
+"""Deterministic, RNG-free synthetic inputs for the hot path (SURVEY.md 8(d) "Synthetic inputs").
+
+No dataset or checkpoint ships with the reference (SMPL assets / PeopleSnapshot are licensed
+and absent), so tests, smoke() and bench.py build their inputs here: a splitmix64 integer
+hash gives bit-identical tensors on every machine without touching torch's RNG.
+"""
+import numpy as np
+import torch
+
+SMPL_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21]
+LBS_BMIN = [-0.8, -1.25, -0.4]
+LBS_BMAX = [0.8, 0.95, 0.4]
+
+# (name, out, in, weight_norm) per Linear -- shapes probed from the reference
+SDF_SPEC = [("lin0", 512, 39, True), ("lin1", 512, 512, True), ("lin2", 512, 512, True), ("lin3", 473, 512, True),
+            ("lin4", 512, 512, True), ("lin5", 512, 512, True), ("lin6", 512, 512, True), ("lin7", 512, 512, True),
+            ("lin8", 257, 512, True)]
+DEF_SPEC = [("lin0", 512, 167, False), ("lin1", 512, 512, False), ("lin2", 512, 512, False), ("lin3", 512, 512, False),
+            ("lin4", 3, 512, False)]
+REND_SPEC = [("lin0", 512, 289, True), ("lin1", 512, 512, True), ("lin2", 512, 512, True), ("lin3", 512, 512, True),
+             ("lin4", 3, 512, True)]
+
+
+def _splitmix(idx, seed):
+    with np.errstate(over="ignore"):
+        h = idx.astype(np.uint64) + np.uint64((seed * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+        h ^= h >> np.uint64(30)
+        h *= np.uint64(0xBF58476D1CE4E5B9)
+        h ^= h >> np.uint64(27)
+        h *= np.uint64(0x94D049BB133111EB)
+        h ^= h >> np.uint64(31)
+    return h
+
+
+def det_array(shape, seed, scale=1.0, dtype=np.float32):
+    """Uniform in [-scale, scale), a pure function of (shape, seed)."""
+    n = int(np.prod(shape))
+    h = _splitmix(np.arange(n, dtype=np.uint64), seed)
+    u = (h >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)
+    return ((u * 2.0 - 1.0) * scale).astype(dtype).reshape(shape)
+
+
+def det_tensor(shape, seed, scale=1.0, dtype=torch.float32):
+    return torch.from_numpy(det_array(shape, seed, scale, np.float64)).to(dtype)
+
+
+def det_params(spec, seed, last_scale=None):
+    """state_dict (reference key names) filled with bounded pseudo-random values that keep
+    activations O(1): rows of variance 2/out (the reference's own init scale, network.py:60-63)."""
+    sd = {}
+    for li, (name, out, inp, wn) in enumerate(spec):
+        std = np.sqrt(2.0 / out) if out > 8 else 0.02
+        w = det_tensor((out, inp), seed * 100 + li * 3, np.sqrt(3.0) * std)
+        b = det_tensor((out,), seed * 100 + li * 3 + 1, 0.05)
+        if last_scale is not None and li == len(spec) - 1:
+            w, b = w * last_scale, b * last_scale
+        if wn:
+            sd[f"{name}.weight_g"] = 1.0 + 0.3 * det_tensor((out, 1), seed * 100 + li * 3 + 2, 1.0)
+            sd[f"{name}.weight_v"] = w
+        else:
+            sd[f"{name}.weight"] = w
+        sd[f"{name}.bias"] = b
+    return sd
+
+
+def synthetic_joints():
+    """Fixed 24-point stick figure in the LBS box, SMPL joint order."""
+    J = np.zeros((24, 3), np.float32)
+    J[0] = [0.0, -0.25, 0.0]                      # pelvis
+    J[1], J[2] = [0.09, -0.33, 0.0], [-0.09, -0.33, 0.0]
+    J[3] = [0.0, -0.12, -0.02]
+    J[4], J[5] = [0.10, -0.70, 0.0], [-0.10, -0.70, 0.0]
+    J[6] = [0.0, 0.02, -0.01]
+    J[7], J[8] = [0.09, -1.08, -0.03], [-0.09, -1.08, -0.03]
+    J[9] = [0.0, 0.08, 0.0]
+    J[10], J[11] = [0.11, -1.14, 0.08], [-0.11, -1.14, 0.08]
+    J[12] = [0.0, 0.28, -0.02]
+    J[13], J[14] = [0.08, 0.19, -0.01], [-0.08, 0.19, -0.01]
+    J[15] = [0.0, 0.37, 0.03]
+    J[16], J[17] = [0.19, 0.21, -0.02], [-0.19, 0.21, -0.02]
+    J[18], J[19] = [0.44, 0.20, -0.03], [-0.44, 0.20, -0.03]
+    J[20], J[21] = [0.69, 0.21, -0.02], [-0.69, 0.21, -0.02]
+    J[22], J[23] = [0.77, 0.20, -0.03], [-0.77, 0.20, -0.03]
+    return torch.from_numpy(J)
+
+
+def synthetic_lbs_volume(shape_dhw=(65, 225, 129), device="cpu", chunk=1 << 20):
+    """ws = softmax_j(-4 |voxel - J_j|^2 / 0.15^2), shape (1,24,D,H,W); voxel centres follow
+    the reference's align_corners=False convention (model/Deformer.py:246-262)."""
+    D, H, W = shape_dhw
+    J = synthetic_joints().to(device)
+    bmin = torch.tensor(LBS_BMIN, device=device)
+    bmax = torch.tensor(LBS_BMAX, device=device)
+    zs, ys, xs = torch.meshgrid(torch.arange(D, device=device), torch.arange(H, device=device),
+                                torch.arange(W, device=device), indexing="ij")
+    c = torch.stack([xs, ys, zs], -1).reshape(-1, 3).float()
+    res = torch.tensor([W, H, D], device=device).float()
+    c = (c / res + 0.5 / res) * (bmax - bmin) + bmin
+    outs = []
+    for part in torch.split(c, chunk):
+        d2 = ((part[:, None, :] - J[None]) ** 2).sum(-1)
+        outs.append(torch.softmax(-4.0 * d2 / (0.15 ** 2), dim=1))
+    w = torch.cat(outs, 0)
+    return w.t().reshape(1, 24, D, H, W).contiguous()
+
+
+def det_normal(shape, seed, std=1.0, mean=0.0):
+    """Approximately normal (Irwin-Hall, 4 uniforms): adds/muls only, so bit-reproducible."""
+    s = sum(det_array(shape, seed * 4 + k, 1.0, np.float64) for k in range(4)) * (np.sqrt(3.0) / 2.0)
+    return torch.from_numpy(s * std + mean).float()
+
+
+def sphere_sdf_params(seed=7, bias=0.6, multires=6, feat=256):
+    """A state_dict following the reference's geometric initialisation rules
+    (model/network.py:49-63: sphere of radius `bias`), drawn from det_normal instead of
+    torch's RNG so that tests / bench get the same near-sphere SDF everywhere."""
+    dims = [3 + 6 * multires] + [512] * 8 + [1 + feat]
+    skip_in = (4,)
+    sd = {}
+    nl = len(dims)
+    for l in range(nl - 1):
+        out_dim = dims[l + 1] - dims[0] if (l + 1) in skip_in else dims[l + 1]
+        k = dims[l]
+        if l == nl - 2:
+            w = det_normal((out_dim, k), seed * 50 + l, 0.0001, np.sqrt(np.pi) / np.sqrt(k))
+            b = torch.full((out_dim,), -bias)
+        elif l == 0:
+            w = torch.zeros(out_dim, k)
+            w[:, :3] = det_normal((out_dim, 3), seed * 50 + l, np.sqrt(2) / np.sqrt(out_dim))
+            b = torch.zeros(out_dim)
+        elif l in skip_in:
+            w = det_normal((out_dim, k), seed * 50 + l, np.sqrt(2) / np.sqrt(out_dim))
+            w[:, -(dims[0] - 3):] = 0.0
+            b = torch.zeros(out_dim)
+        else:
+            w = det_normal((out_dim, k), seed * 50 + l, np.sqrt(2) / np.sqrt(out_dim))
+            b = torch.zeros(out_dim)
+        sd[f"lin{l}.weight_g"] = w.double().norm(dim=1, keepdim=True).float()
+        sd[f"lin{l}.weight_v"] = w
+        sd[f"lin{l}.bias"] = b
+    return sd
