@@ -1,0 +1,82 @@
+/* selfrecon_hip.h -- flat C ABI of libselfrecon_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary of the SelfRecon per-frame SDF-optimisation hot path: every entry
+ * point replaces one pybind/CUDA surface of the reference (cited per function, paths
+ * relative to the reference repository).  Conventions, all functions:
+ *   - return 0 on success, a negative SR_E* code otherwise; nothing is allocated inside;
+ *     the caller owns every buffer; all pointers are DEVICE pointers unless named host_*;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are
+ *     asynchronous and re-entrant per stream; no global mutable state except explicit
+ *     workspaces passed by the caller;
+ *   - tensors are dense row-major unless strides are passed explicitly (in ELEMENTS).
+ * The Python host (selfreconcode_amd/) maps non-zero codes to the reference's own error
+ * convention (exception; empty list for mc_gpu -- MCGpu/MCGpu.cpp:41-48).
+ */
+#ifndef SELFRECON_HIP_H_
+#define SELFRECON_HIP_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR_OK 0
+#define SR_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported mode) */
+#define SR_ELAUNCH (-2)  /* hipGetLastError() after launch != hipSuccess */
+#define SR_ENOSPC (-3)   /* caller-provided workspace / output capacity too small */
+
+int sr_abi_version(void);            /* bumps when a signature below changes */
+const char* sr_build_arch(void);     /* "gfx950" */
+
+/* ---------------------------------------------------------------- FastMinv (a7)
+ * Replaces FastMinv/M3x3Inv.cpp:12-38 Fast3x3Minv -> Matrix3x3InvKernels.cu:22-61 and
+ * M3x3Inv.cpp:40-58 Fast3x3Minv_backward -> Matrix3x3InvKernels.cu:64-104.
+ * ms/invs/grads/outs: [n,3,3]; checks: [n] bytes (0/1).  Singular rule: |det| < 1e-4
+ * -> inverse = 0, check = 0.  backward: out = -(C^T G C^T), C = saved inverse. */
+int sr_minv3x3_fwd_f32(const float* ms, float* invs, uint8_t* checks, int64_t n, void* stream);
+int sr_minv3x3_fwd_f64(const double* ms, double* invs, uint8_t* checks, int64_t n, void* stream);
+int sr_minv3x3_bwd_f32(const float* grads, const float* invs, float* outs, int64_t n, void* stream);
+int sr_minv3x3_bwd_f64(const double* grads, const double* invs, double* outs, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------- GridSamplerMine (a6)
+ * Replaces MCAcc/cuda/GridSamplerMine.cpp:73-104 (forward / backward / dbackward) ->
+ * GridSamplerMineKernel.cu:162-328, 333-570, 575-914.  Trilinear, border padding,
+ * align_corners=False only (the only mode the reference accepts, GridSamplerMine.cpp:59-64).
+ * A tensor is described by its 5 sizes / strides in elements: input [N,C,D,H,W];
+ * grid [N,Do,Ho,Wo,3]; output-like tensors [N,C,Do,Ho,Wo].  grad_grid is dense [N,Do,Ho,Wo,3]
+ * (the reference assumes the same, Kernel.cu:538-545).  grad_input may be NULL (skip it: the
+ * skinning-weight volume is a buffer) -- when given it must be ZERO-FILLED by the caller and has
+ * the input's sizes with its own strides. */
+typedef struct {
+  int64_t size[5];
+  int64_t stride[5];
+} sr_tensor5;
+
+int sr_gridsample3d_fwd_f32(const float* input, sr_tensor5 in_d, const float* grid, sr_tensor5 grid_d,
+                            float* output, sr_tensor5 out_d, void* stream);
+int sr_gridsample3d_fwd_f64(const double* input, sr_tensor5 in_d, const double* grid, sr_tensor5 grid_d,
+                            double* output, sr_tensor5 out_d, void* stream);
+int sr_gridsample3d_bwd_f32(const float* input, sr_tensor5 in_d, const float* grid, sr_tensor5 grid_d,
+                            const float* grad_output, sr_tensor5 gout_d,
+                            float* grad_input /*nullable*/, sr_tensor5 gin_d, float* grad_grid, void* stream);
+int sr_gridsample3d_bwd_f64(const double* input, sr_tensor5 in_d, const double* grid, sr_tensor5 grid_d,
+                            const double* grad_output, sr_tensor5 gout_d,
+                            double* grad_input /*nullable*/, sr_tensor5 gin_d, double* grad_grid, void* stream);
+/* double backward: cotangents (gO_input [like input] nullable = zeros, gO_grid [N,Do,Ho,Wo,3]
+ * with strides) of the backward's two outputs -> grad_input (nullable, zero-filled by caller),
+ * grad_grid (dense), grad_grad_output (dense [N,C,Do,Ho,Wo]). */
+int sr_gridsample3d_dbwd_f32(const float* gO_input /*nullable*/, sr_tensor5 goi_d, const float* gO_grid, sr_tensor5 gog_d,
+                             const float* input, sr_tensor5 in_d, const float* grid, sr_tensor5 grid_d,
+                             const float* grad_output, sr_tensor5 gout_d,
+                             float* grad_input /*nullable*/, sr_tensor5 gin_d, float* grad_grid, float* grad_grad_output,
+                             void* stream);
+int sr_gridsample3d_dbwd_f64(const double* gO_input /*nullable*/, sr_tensor5 goi_d, const double* gO_grid, sr_tensor5 gog_d,
+                             const double* input, sr_tensor5 in_d, const double* grid, sr_tensor5 grid_d,
+                             const double* grad_output, sr_tensor5 gout_d,
+                             double* grad_input /*nullable*/, sr_tensor5 gin_d, double* grad_grid, double* grad_grad_output,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SELFRECON_HIP_H_ */

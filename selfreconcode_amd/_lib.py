@@ -1,0 +1,95 @@
+"""ctypes binding of libselfrecon_hip.so -- the only door from Python to the HIP kernels.
+
+There is NO fallback: if the shared library is missing or lacks a symbol the import of any
+operator module fails loudly (a product path that silently ran on CPU/eager PyTorch would
+void every parity and performance claim).
+"""
+import ctypes
+import os
+import torch
+
+from .build import LIB
+
+_i64, _vp, _int = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
+
+
+class SrTensor5(ctypes.Structure):
+    _fields_ = [("size", _i64 * 5), ("stride", _i64 * 5)]
+
+
+class SrError(RuntimeError):
+    pass
+
+
+_CODES = {-1: "SR_EINVAL (bad argument)", -2: "SR_ELAUNCH (kernel launch failed)", -3: "SR_ENOSPC (workspace too small)"}
+
+if not os.path.isfile(LIB):
+    raise ImportError(f"{LIB} not found: run `python -m selfreconcode_amd.build` (hipcc --offload-arch=gfx950). "
+                      "There is no CPU fallback for the HIP hot path.")
+_lib = ctypes.CDLL(LIB)
+
+# name -> argtypes; mirrors include/selfrecon_hip.h one to one (tests/test_abi.py checks the set)
+_T5 = SrTensor5
+SIGNATURES = {
+    "sr_minv3x3_fwd_f32": [_vp, _vp, _vp, _i64, _vp],
+    "sr_minv3x3_fwd_f64": [_vp, _vp, _vp, _i64, _vp],
+    "sr_minv3x3_bwd_f32": [_vp, _vp, _vp, _i64, _vp],
+    "sr_minv3x3_bwd_f64": [_vp, _vp, _vp, _i64, _vp],
+    "sr_gridsample3d_fwd_f32": [_vp, _T5, _vp, _T5, _vp, _T5, _vp],
+    "sr_gridsample3d_fwd_f64": [_vp, _T5, _vp, _T5, _vp, _T5, _vp],
+    "sr_gridsample3d_bwd_f32": [_vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _vp],
+    "sr_gridsample3d_bwd_f64": [_vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _vp],
+    "sr_gridsample3d_dbwd_f32": [_vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _vp, _vp],
+    "sr_gridsample3d_dbwd_f64": [_vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _vp, _vp],
+}
+
+_fn = {}
+for _name, _args in SIGNATURES.items():
+    try:
+        _f = getattr(_lib, _name)
+    except AttributeError as e:  # pragma: no cover
+        raise ImportError(f"{LIB} does not export {_name}; rebuild it") from e
+    _f.argtypes = _args
+    _f.restype = _int
+    _fn[_name] = _f
+_lib.sr_abi_version.restype = _int
+_lib.sr_build_arch.restype = ctypes.c_char_p
+
+
+def abi_version():
+    return _lib.sr_abi_version()
+
+
+def build_arch():
+    return _lib.sr_build_arch().decode()
+
+
+def call(name, *args):
+    rc = _fn[name](*args)
+    if rc != 0:
+        raise SrError(f"{name} failed: {_CODES.get(rc, rc)}")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_of(t):
+    """hipStream_t of torch's CURRENT stream on the tensor's device (kernels are stream-ordered
+    with the surrounding torch ops; the reference's FastMinv/MCGpu used the legacy default stream)."""
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def desc5(t):
+    d = SrTensor5()
+    for i in range(5):
+        d.size[i] = t.shape[i]
+        d.stride[i] = t.stride(i)
+    return d
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("selfreconcode_amd: HIP operator called with a non-GPU tensor "
+                               "(there is deliberately no CPU fallback)")

@@ -1,0 +1,111 @@
+// Batched closed-form 3x3 inverse + analytic backward.
+// Behaviour follows FastMinv/Matrix3x3InvKernels.cu:22-104 (adjugate/det, |det|<1e-4 -> zeros+false;
+// backward -(C^T G C^T)).  HBM-bound (73 B/matrix fwd, 108 B/matrix bwd): a workgroup moves
+// 256 matrices (2304 scalars) through LDS so that every global access is a coalesced dword
+// stream; the stride-9 LDS reads are conflict-free (9 is odd).
+#include "sr_common.h"
+
+namespace {
+constexpr int kMat = 256;  // matrices per workgroup == threads per workgroup
+
+template <typename T>
+__global__ __launch_bounds__(kMat) void minv_fwd_kernel(const T* __restrict__ ms, T* __restrict__ invs,
+                                                         uint8_t* __restrict__ checks, int64_t n) {
+  __shared__ T tile[kMat * 9];
+  for (int64_t base = (int64_t)blockIdx.x * kMat; base < n; base += (int64_t)gridDim.x * kMat) {
+    const int64_t left = n - base;
+    const int cnt = left < kMat ? (int)left : kMat;
+    const T* src = ms + base * 9;
+    for (int i = threadIdx.x; i < cnt * 9; i += kMat) tile[i] = src[i];
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < cnt) {
+      T* m = tile + t * 9;
+      const T m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5], m20 = m[6], m21 = m[7], m22 = m[8];
+      const T c00 = m11 * m22 - m12 * m21;
+      const T c01 = -m10 * m22 + m12 * m20;
+      const T c02 = m10 * m21 - m11 * m20;
+      const T c10 = -m01 * m22 + m02 * m21;
+      const T c11 = m00 * m22 - m02 * m20;
+      const T c12 = -m00 * m21 + m01 * m20;
+      const T c20 = m01 * m12 - m02 * m11;
+      const T c21 = -m00 * m12 + m02 * m10;
+      const T c22 = m00 * m11 - m01 * m10;
+      const T det = m00 * c00 + m01 * c01 + m02 * c02;
+      const bool singular = fabs((double)det) < 0.0001;
+      if (singular) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) m[i] = T(0);
+      } else {
+        m[0] = c00 / det; m[1] = c10 / det; m[2] = c20 / det;
+        m[3] = c01 / det; m[4] = c11 / det; m[5] = c21 / det;
+        m[6] = c02 / det; m[7] = c12 / det; m[8] = c22 / det;
+      }
+      checks[base + t] = singular ? 0 : 1;
+    }
+    __syncthreads();
+    T* dst = invs + base * 9;
+    for (int i = threadIdx.x; i < cnt * 9; i += kMat) dst[i] = tile[i];
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kMat) void minv_bwd_kernel(const T* __restrict__ grads, const T* __restrict__ invs,
+                                                         T* __restrict__ outs, int64_t n) {
+  __shared__ T gt[kMat * 9];
+  __shared__ T ct[kMat * 9];
+  for (int64_t base = (int64_t)blockIdx.x * kMat; base < n; base += (int64_t)gridDim.x * kMat) {
+    const int64_t left = n - base;
+    const int cnt = left < kMat ? (int)left : kMat;
+    for (int i = threadIdx.x; i < cnt * 9; i += kMat) {
+      gt[i] = grads[base * 9 + i];
+      ct[i] = invs[base * 9 + i];
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < cnt) {
+      T g[9], c[9], tmp[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { g[i] = gt[t * 9 + i]; c[i] = ct[t * 9 + i]; }
+      // tmp = C^T G ; out = -(tmp C^T):  out[a][b] = -sum_{i,j} C[i][a] G[i][j] C[b][j]
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) tmp[a * 3 + j] = c[0 * 3 + a] * g[0 * 3 + j] + c[1 * 3 + a] * g[1 * 3 + j] + c[2 * 3 + a] * g[2 * 3 + j];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          gt[t * 9 + a * 3 + b] = -(tmp[a * 3 + 0] * c[b * 3 + 0] + tmp[a * 3 + 1] * c[b * 3 + 1] + tmp[a * 3 + 2] * c[b * 3 + 2]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt * 9; i += kMat) outs[base * 9 + i] = gt[i];
+    __syncthreads();
+  }
+}
+
+template <typename T>
+int minv_fwd(const T* ms, T* invs, uint8_t* checks, int64_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!ms || !invs || !checks))) return SR_EINVAL;
+  if (n == 0) return SR_OK;
+  hipLaunchKernelGGL(minv_fwd_kernel<T>, dim3(sr_stream_grid(n, kMat)), dim3(kMat), 0, (hipStream_t)stream, ms, invs, checks, n);
+  return sr_launch_status();
+}
+template <typename T>
+int minv_bwd(const T* grads, const T* invs, T* outs, int64_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!grads || !invs || !outs))) return SR_EINVAL;
+  if (n == 0) return SR_OK;
+  hipLaunchKernelGGL(minv_bwd_kernel<T>, dim3(sr_stream_grid(n, kMat)), dim3(kMat), 0, (hipStream_t)stream, grads, invs, outs, n);
+  return sr_launch_status();
+}
+}  // namespace
+
+extern "C" {
+int sr_abi_version(void) { return 1; }
+const char* sr_build_arch(void) { return "gfx950"; }
+int sr_minv3x3_fwd_f32(const float* ms, float* invs, uint8_t* checks, int64_t n, void* s) { return minv_fwd<float>(ms, invs, checks, n, s); }
+int sr_minv3x3_fwd_f64(const double* ms, double* invs, uint8_t* checks, int64_t n, void* s) { return minv_fwd<double>(ms, invs, checks, n, s); }
+int sr_minv3x3_bwd_f32(const float* g, const float* i, float* o, int64_t n, void* s) { return minv_bwd<float>(g, i, o, n, s); }
+int sr_minv3x3_bwd_f64(const double* g, const double* i, double* o, int64_t n, void* s) { return minv_bwd<double>(g, i, o, n, s); }
+}

@@ -1,0 +1,101 @@
+"""GPU parity of the extension-op drop-ins (FastMinv, GridSamplerMine) through the C ABI,
+against the CPU oracle on the same seeded inputs."""
+import pytest
+import torch
+from oracle import torch_oracle as orc
+from oracle import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float64, 1e-12)])
+@pytest.mark.parametrize("n", [0, 1, 255, 257, 10000])
+def test_minv_forward_backward(dtype, tol, n):
+    from selfreconcode_amd.ext.FastMinv import Fast3x3Minv, Fast3x3Minv_backward
+    m = fx.det_tensor((n, 3, 3), 71 + n, 1.5, dtype)
+    if n > 9:
+        m[5] = 0; m[9, 2] = m[9, 1]          # singular rows -> zeros + False (Matrix3x3InvKernels.cu:40-47)
+    inv_o, ok_o = orc.minv3x3(m)
+    inv, ok = Fast3x3Minv(m.to(DEV))
+    assert inv.shape == (n, 3, 3) and ok.dtype == torch.bool
+    assert torch.equal(ok.cpu(), ok_o)
+    torch.testing.assert_close(inv.cpu(), inv_o, rtol=tol, atol=tol * 10)
+    if n:
+        good = ok.cpu()
+        err = (inv.cpu()[good] @ m[good] - torch.eye(3, dtype=dtype)).norm(dim=(1, 2))   # FastMinv/check.py property
+        assert err.max() < (5e-2 if dtype == torch.float32 else 1e-7)
+    g = fx.det_tensor((n, 3, 3), 3, 1.0, dtype)
+    out = Fast3x3Minv_backward(g.to(DEV), inv)
+    torch.testing.assert_close(out.cpu(), orc.minv3x3_backward(g, inv_o), rtol=tol * 10, atol=tol * 100)
+
+
+def test_minv_argument_errors():
+    from selfreconcode_amd.ext.FastMinv import Fast3x3Minv
+    with pytest.raises(RuntimeError):
+        Fast3x3Minv(torch.zeros(4, 3, 3, device=DEV).transpose(1, 2))      # non contiguous
+    with pytest.raises(RuntimeError):
+        Fast3x3Minv(torch.zeros(4, 3, 3, device=DEV, dtype=torch.half))
+
+
+def _gs_case(dtype, C=5, shape=(15, 15, 15), P=10, seed=0, span=1.1, channel_last=False):
+    inp = fx.det_tensor((1, C) + shape, 100 + seed, 1.0, dtype)
+    grid = fx.det_tensor((1, 1, 1, P, 3), 200 + seed, span, dtype)
+    if channel_last:
+        inp = inp.permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)
+    return inp, grid
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.float64, 1e-11)])
+@pytest.mark.parametrize("channel_last", [False, True])
+def test_gridsample_fwd_bwd_dbwd_vs_oracle(dtype, tol, channel_last):
+    from selfreconcode_amd.MCAcc import GridSamplerMine3dFunction
+    inp, grid = _gs_case(dtype, C=24, shape=(7, 11, 9), P=300, seed=1, span=1.15, channel_last=channel_last)
+    go = fx.det_tensor((1, 24, 1, 1, 300), 5, 1.0, dtype)
+    u = fx.det_tensor((1, 1, 1, 300, 3), 6, 1.0, dtype)
+
+    def run(fn, dev):
+        i = inp.to(dev).requires_grad_(True)
+        g = grid.to(dev).requires_grad_(True)
+        out = fn(i, g)
+        gi, gg = torch.autograd.grad(out, [i, g], go.to(dev), create_graph=True)
+        s = (gg * u.to(dev)).sum() + (gi * gi.detach()).sum() * 0.5
+        d_i, d_g = torch.autograd.grad(s, [i, g])
+        return [t.detach().cpu() for t in (out, gi, gg, d_i, d_g)]
+
+    ours = run(GridSamplerMine3dFunction.apply, DEV)
+    ref = run(orc.grid_sample_3d, "cpu")
+    for a, b, name in zip(ours, ref, ["out", "grad_input", "grad_grid", "dd_input", "dd_grid"]):
+        torch.testing.assert_close(a, b, rtol=tol * 20, atol=tol * 20, msg=lambda m, n=name: f"{n}: {m}")
+
+
+def test_gridsample_matches_aten_value():
+    """the identity the reference leans on: GridSamplerMine == F.grid_sample(border, align_corners=False)"""
+    from selfreconcode_amd.ext import GridSamplerMine
+    inp, grid = _gs_case(torch.float32, C=6, shape=(9, 8, 7), P=2000, seed=3, span=1.3)
+    out = GridSamplerMine.forward(inp.to(DEV), grid.to(DEV), 0, 1)
+    ref = torch.nn.functional.grid_sample(inp, grid, mode='bilinear', padding_mode='border', align_corners=False)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_gridsample_gradcheck_like_reference_script():
+    """MCAcc/check_grid_sampler_mine.py: f64 gradcheck of fwd->bwd and of bwd->double-bwd,
+    input (1,5,15,15,15), grid (1,1,1,10,3) in [-1.1,1.1]."""
+    from selfreconcode_amd.MCAcc import GridSamplerMine3dFunction, GridSamplerMine3dBackwardFunction
+    inp, grid = _gs_case(torch.float64)
+    inp = inp.to(DEV).requires_grad_(True)
+    grid = grid.to(DEV).requires_grad_(True)
+    assert torch.autograd.gradcheck(GridSamplerMine3dFunction.apply, (inp, grid))
+    go = fx.det_tensor((1, 5, 1, 1, 10), 9, 1.0, torch.float64).to(DEV).requires_grad_(True)
+    assert torch.autograd.gradcheck(GridSamplerMine3dBackwardFunction.apply, (inp, grid, go))
+
+
+def test_gridsample_argument_errors_and_empty():
+    from selfreconcode_amd.ext import GridSamplerMine
+    inp, grid = _gs_case(torch.float32)
+    with pytest.raises(RuntimeError):
+        GridSamplerMine.forward(inp.to(DEV), grid.to(DEV), 1, 1)          # nearest: unsupported like the reference
+    with pytest.raises(RuntimeError):
+        GridSamplerMine.forward(inp.to(DEV), grid.to(DEV).double(), 0, 1)
+    out = GridSamplerMine.forward(inp.to(DEV), grid[:, :, :, :0].to(DEV), 0, 1)
+    assert out.shape == (1, 5, 1, 1, 0)
