@@ -76,6 +76,66 @@ int sr_gridsample3d_dbwd_f64(const double* gO_input /*nullable*/, sr_tensor5 goi
                              double* grad_input /*nullable*/, sr_tensor5 gin_d, double* grad_grid, double* grad_grad_output,
                              void* stream);
 
+
+/* ---------------------------------------------------------------- MLP layer kernels (a2, a3, a4, a10)
+ * Replace the per-layer nn.Linear (cuBLAS) + activation + torch.cat launches of
+ * model/network.py:83-95 (ImplicitNetwork.forward), model/Deformer.py:66-71 (MLPTranslator),
+ * model/RenderNet.py:80-88, and their autograd backward / double-backward passes
+ * (network.py:102-114, utils/utils.py:106-120).  Exact fp32 on the MFMA pipe
+ * (v_mfma_f32_32x32x2_f32); rows are "tangent-interleaved": each sample owns `group` (1, 2 or 4)
+ * consecutive rows = primal + forward-mode tangents.
+ *
+ * sr_mlp_gemm_nt:  C[M, N(+naux_fwd)] = epilogue( A[M,K] * B[N,K]^T )
+ *   SR_EPI_FWD : primal rows  c = act(acc + bias) * out_scale
+ *                tangent rows c = act'(primal pre-activation) * acc * out_scale
+ *                columns [N, N+naux_fwd) = aux[:, 0:naux_fwd] * out_scale       (skip concat, network.py:88-89)
+ *   SR_EPI_BWD : acc is the cotangent of the STORED activations `aux` (= aux_scale * act(z), same row layout)
+ *                columns < nact_bwd: primal  c = act' * aux_scale * acc + (act''/act') * sum_t aux_t * acc_t
+ *                                    tangent c = act' * aux_scale * acc
+ *                columns >= nact_bwd: c = acc * out_scale                       (cotangent of the skip filler)
+ * Requirements: lda, ldb multiples of 4 floats and A, B 16-byte aligned; M % group == 0. */
+#define SR_ACT_NONE 0
+#define SR_ACT_SOFTPLUS100 1   /* torch.nn.Softplus(beta=100, threshold=20), network.py:70 */
+#define SR_ACT_RELU 2
+#define SR_EPI_FWD 0
+#define SR_EPI_BWD 1
+typedef struct {
+  const float* A; int64_t lda;
+  const float* B; int64_t ldb;
+  float* C; int64_t ldc;
+  int32_t M, N, K;
+  const float* bias;      /* [N] or NULL; primal rows only */
+  int32_t group, act, mode;
+  float out_scale;
+  const float* aux; int64_t ldaux;
+  int32_t naux_fwd;       /* FWD: number of filler columns appended after N */
+  int32_t nact_bwd;       /* BWD: leading columns that go through the activation derivative */
+  float aux_scale;        /* BWD: scale the stored activations carry */
+} sr_gemm_args;
+int sr_mlp_gemm_nt(const sr_gemm_args* host_args, void* stream);
+
+/* Weight gradient: dW[N, lddw] (+)= sum_r Z[r, 0:N]^T A[r, 0:K], all rows (primal and tangent).
+ * Split over r into `splits` slabs in `partial` (>= splits*N*lddw floats, see _workspace_floats),
+ * reduced in a fixed order (deterministic).  accumulate != 0 adds into dW. */
+typedef struct {
+  const float* Z; int64_t ldz;
+  const float* A; int64_t lda;
+  float* dW; int64_t lddw;
+  float* partial;
+  int32_t R, N, K, splits, accumulate;
+} sr_gemm_tn_args;
+int64_t sr_mlp_gemm_tn_workspace_floats(int32_t R, int32_t N, int64_t lddw, int32_t* host_splits_out);
+int sr_mlp_gemm_tn(const sr_gemm_tn_args* host_args, void* stream);
+/* Bias gradient: out[n] += sum_{r % group == 0} Z[r][n]  (out must be zero-filled or hold the running sum). */
+int sr_colsum_rows(const float* Z, int64_t ldz, int32_t R, int32_t N, int32_t group, float* out, void* stream);
+
+/* Positional encoding (a1) fused with the first-layer input assembly: replaces the 13 elementwise
+ * launches + torch.cat of model/Embedder.py:34-41 and the conds[batch_inds] concat of
+ * model/Deformer.py:58-61.  out[p*group, :] = [x | w sin/cos bands | extra[extra_index[p] or p] | 0];
+ * group == 4 also writes the three d/dx_t seed-tangent rows.  band_weights: 2*L floats (device). */
+int sr_pe_embed(const float* x, int64_t P, int32_t L, const float* band_weights, const float* extra, int64_t ldextra,
+                int32_t E, const int64_t* extra_index /*nullable*/, int32_t group, float* out, int64_t ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,20 @@ class SrTensor5(ctypes.Structure):
     _fields_ = [("size", _i64 * 5), ("stride", _i64 * 5)]
 
 
+class SrGemmArgs(ctypes.Structure):
+    _fields_ = [("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("C", _vp), ("ldc", _i64),
+                ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("bias", _vp),
+                ("group", ctypes.c_int32), ("act", ctypes.c_int32), ("mode", ctypes.c_int32), ("out_scale", ctypes.c_float),
+                ("aux", _vp), ("ldaux", _i64), ("naux_fwd", ctypes.c_int32), ("nact_bwd", ctypes.c_int32),
+                ("aux_scale", ctypes.c_float)]
+
+
+class SrGemmTnArgs(ctypes.Structure):
+    _fields_ = [("Z", _vp), ("ldz", _i64), ("A", _vp), ("lda", _i64), ("dW", _vp), ("lddw", _i64), ("partial", _vp),
+                ("R", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("splits", ctypes.c_int32),
+                ("accumulate", ctypes.c_int32)]
+
+
 class SrError(RuntimeError):
     pass
 
@@ -41,7 +55,13 @@ SIGNATURES = {
     "sr_gridsample3d_bwd_f64": [_vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _vp],
     "sr_gridsample3d_dbwd_f32": [_vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _vp, _vp],
     "sr_gridsample3d_dbwd_f64": [_vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _vp, _vp],
+    "sr_mlp_gemm_nt": [_vp, _vp],
+    "sr_mlp_gemm_tn_workspace_floats": [ctypes.c_int32, ctypes.c_int32, _i64, _vp],
+    "sr_mlp_gemm_tn": [_vp, _vp],
+    "sr_colsum_rows": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
+    "sr_pe_embed": [_vp, _i64, ctypes.c_int32, _vp, _vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _i64, _vp],
 }
+_RESTYPE = {"sr_mlp_gemm_tn_workspace_floats": _i64}
 
 _fn = {}
 for _name, _args in SIGNATURES.items():
@@ -50,7 +70,7 @@ for _name, _args in SIGNATURES.items():
     except AttributeError as e:  # pragma: no cover
         raise ImportError(f"{LIB} does not export {_name}; rebuild it") from e
     _f.argtypes = _args
-    _f.restype = _int
+    _f.restype = _RESTYPE.get(_name, _int)
     _fn[_name] = _f
 _lib.sr_abi_version.restype = _int
 _lib.sr_build_arch.restype = ctypes.c_char_p
@@ -62,6 +82,10 @@ def abi_version():
 
 def build_arch():
     return _lib.sr_build_arch().decode()
+
+
+def raw(name):
+    return _fn[name]
 
 
 def call(name, *args):

@@ -1,0 +1,479 @@
+// Layer kernels of the three MLPs (SDF a2/a3, deformer a4, render a10): exact-fp32 MFMA GEMMs
+// (v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD = the 157.3 TFLOP/s fp32 roof) with the layer's
+// elementwise work fused into the epilogue.
+//
+// Row layout ("tangent-interleaved rows"): a sample owns `group` = 1, 2 or 4 consecutive rows
+// -- its primal activation followed by up to 3 forward-mode tangents.  The 32x32 MFMA
+// accumulator gives every lane 4 consecutive rows of one column (rows 4q..4q+3 of a quad), so
+// a sample's primal and tangents sit in ONE lane: activation derivatives (softplus'/softplus''
+// or the ReLU mask) are applied in registers, with no cross-lane traffic and no extra pass
+// over HBM.  Forward, backward-data and the second-order terms all run through the same NT
+// kernel (backward-data uses the pre-transposed weight); the weight gradient is a split-R TN
+// kernel with a deterministic slab reduction.
+//
+// Tiling: 128x128x32 per 256-thread workgroup (2x2 waves of 64x64 = 2x2 MFMA blocks, 64
+// accumulator VGPRs), operands staged through LDS in [row][32+4] images -- a 144-byte row pitch
+// makes the ds_read_b128 fragment reads bank-conflict free -- double buffered, with the next
+// tile's global loads issued before the MFMA block of the current one.
+#include "sr_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 32;        // K per tile step
+constexpr int LDSP = BK + 4;  // LDS row pitch in floats (144 B: 16-B aligned, conflict-free b128 reads)
+
+__device__ __forceinline__ float softplus100(float z) {
+  const float t = z * 100.0f;
+  return t > 20.0f ? z : log1pf(expf(t)) / 100.0f;
+}
+__device__ __forceinline__ float dsoftplus100(float z) {  // torch: z*beta > threshold ? 1 : e/(e+1)
+  const float t = z * 100.0f;
+  if (t > 20.0f) return 1.0f;
+  const float e = expf(t);
+  return e / (e + 1.0f);
+}
+
+template <int WM, int WN, int TM, int TN>
+struct Cfg {
+  static constexpr int kWaves = WM * WN;
+  static constexpr int kThreads = kWaves * 64;
+  static constexpr int BM = WM * TM * 32;
+  static constexpr int BN = WN * TN * 32;
+  static constexpr int kALoads = BM * (BK / 4) / kThreads;  // float4 per thread per tile
+  static constexpr int kBLoads = (BN * (BK / 4) + kThreads - 1) / kThreads;
+  static constexpr int kLdsFloats = 2 * (BM + BN) * LDSP;
+};
+
+// Loads a [ROWS x 32] tile (rows r0.., k from k0) as float4 per thread with zero fill outside
+// [0,R) x [0,K).  Requires ld % 4 == 0 and a 16-byte aligned base.
+template <int ROWS, int NLOADS, int THREADS>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t ld, int R, int K, int r0, int k0,
+                                          f32x4 (&reg)[NLOADS]) {
+#pragma unroll
+  for (int j = 0; j < NLOADS; ++j) {
+    const int idx = threadIdx.x + j * THREADS;
+    const int row = idx >> 3, kq = idx & 7;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int gr = r0 + row, gk = k0 + kq * 4;
+    if (idx < ROWS * 8 && gr < R && gk < K) {
+      v = *reinterpret_cast<const f32x4*>(P + (int64_t)gr * ld + gk);
+      if (gk + 3 >= K) {  // ragged K tail inside this float4
+        if (gk + 1 >= K) v.y = 0.f;
+        if (gk + 2 >= K) v.z = 0.f;
+        if (gk + 3 >= K) v.w = 0.f;
+      }
+    }
+    reg[j] = v;
+  }
+}
+
+template <int ROWS, int NLOADS, int THREADS>
+__device__ __forceinline__ void store_tile(float* __restrict__ lds, const f32x4 (&reg)[NLOADS]) {
+#pragma unroll
+  for (int j = 0; j < NLOADS; ++j) {
+    const int idx = threadIdx.x + j * THREADS;
+    const int row = idx >> 3, kq = idx & 7;
+    if (idx < ROWS * 8) *reinterpret_cast<f32x4*>(lds + row * LDSP + kq * 4) = reg[j];
+  }
+}
+
+// Epilogue for one wave: every lane holds, per 32x32 block, 4 quads of 4 consecutive rows (one column).
+// G rows form one sample (primal + G-1 tangents); all per-sample maths is in-register.
+template <int WM, int WN, int TM, int TN, int G>
+__device__ __forceinline__ void epilogue(const sr_gemm_args& g, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                         int li, int kh) {
+  const int ncols = g.N + g.naux_fwd;  // columns of C this launch produces
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = n0 + (wn * TN + b) * 32 + li;
+      if (col >= ncols) continue;
+      const float bias = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r0 = m0 + (wm * TM + a) * 32 + 8 * q + 4 * kh;  // rows r0..r0+3 live in this lane
+        if (r0 >= g.M) continue;
+        float v[4] = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+        float o[4];
+        if (g.mode == SR_EPI_FWD) {
+          if (col >= g.N) {  // skip-concat filler: C[:, N + j] = aux[:, j] * out_scale
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (r0 + j < g.M) ? g.aux[(int64_t)(r0 + j) * g.ldaux + (col - g.N)] * g.out_scale : 0.f;
+          } else {
+#pragma unroll
+            for (int s = 0; s < 4; s += G) {  // one sample: primal row s, tangents s+1..s+G-1
+              const float z = v[s] + bias;
+              float d;
+              if (g.act == SR_ACT_SOFTPLUS100) { o[s] = softplus100(z) * g.out_scale; d = (G > 1) ? dsoftplus100(z) : 0.f; }
+              else if (g.act == SR_ACT_RELU) { o[s] = fmaxf(z, 0.f) * g.out_scale; d = z > 0.f ? 1.f : 0.f; }
+              else { o[s] = z * g.out_scale; d = 1.f; }
+#pragma unroll
+              for (int tI = 1; tI < G; ++tI) o[s + tI] = d * v[s + tI] * g.out_scale;
+            }
+          }
+        } else {  // SR_EPI_BWD: acc = cotangent of the STORED activations; emit cotangent of pre-activations
+          if (col >= g.nact_bwd) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = v[j] * g.out_scale;
+          } else {
+            float sv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sv[j] = (r0 + j < g.M) ? g.aux[(int64_t)(r0 + j) * g.ldaux + col] : 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; s += G) {
+              float d, c2;
+              if (g.act == SR_ACT_SOFTPLUS100) {
+                // stored = aux_scale * softplus(z);  1 + e^{100 z} = e^{100 a}  =>  sigma' = 1 - e^{-100 a},
+                // sigma''/sigma' = 100 e^{-100 a}  (both exact identities, no division by sigma')
+                const float x = 100.0f * (sv[s] / g.aux_scale);
+                const float em = expf(-x);
+                d = x < 0.1f ? -expm1f(-x) : 1.0f - em;
+                c2 = 100.0f * em;
+              } else if (g.act == SR_ACT_RELU) { d = sv[s] > 0.f ? 1.f : 0.f; c2 = 0.f; }
+              else { d = 1.f; c2 = 0.f; }
+              float cross = 0.f;
+#pragma unroll
+              for (int tI = 1; tI < G; ++tI) {
+                cross += sv[s + tI] * v[s + tI];           // stored tangent activation x its cotangent
+                o[s + tI] = d * g.aux_scale * v[s + tI];
+              }
+              o[s] = d * g.aux_scale * v[s] + c2 * cross;
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (r0 + j < g.M) g.C[(int64_t)(r0 + j) * g.ldc + col] = o[j];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C = epilogue(A[M,K] * B[N,K]^T)
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(sr_gemm_args g) {
+  using C_ = Cfg<WM, WN, TM, TN>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  auto As = [&](int buf) -> float* { return smem + buf * (C_::BM * LDSP); };
+  auto Bs = [&](int buf) -> float* { return smem + 2 * C_::BM * LDSP + buf * (C_::BN * LDSP); };
+
+  // XCD-aware tile order: consecutive workgroups land on different XCDs (block b -> XCD b%8), so give
+  // each XCD a contiguous run of M-tiles sharing the same weight panel in its private L2.
+  const int tiles_n = (g.N + g.naux_fwd + C_::BN - 1) / C_::BN;
+  const int tiles_m = (g.M + C_::BM - 1) / C_::BM;
+  const int nwg = tiles_m * tiles_n;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, loc = wg / 8;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tn = wg % tiles_n, tm = wg / tiles_n;
+  const int m0 = tm * C_::BM, n0 = tn * C_::BN;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, kh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  f32x4 ra[C_::kALoads], rb[C_::kBLoads];
+  const int nk = (g.K + BK - 1) / BK;
+  load_tile<C_::BM, C_::kALoads, C_::kThreads>(g.A, g.lda, g.M, g.K, m0, 0, ra);
+  load_tile<C_::BN, C_::kBLoads, C_::kThreads>(g.B, g.ldb, g.N, g.K, n0, 0, rb);
+  store_tile<C_::BM, C_::kALoads, C_::kThreads>(As(0), ra);
+  store_tile<C_::BN, C_::kBLoads, C_::kThreads>(Bs(0), rb);
+  __syncthreads();
+
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nk) {
+      load_tile<C_::BM, C_::kALoads, C_::kThreads>(g.A, g.lda, g.M, g.K, m0, (t + 1) * BK, ra);
+      load_tile<C_::BN, C_::kBLoads, C_::kThreads>(g.B, g.ldb, g.N, g.K, n0, (t + 1) * BK, rb);
+    }
+    const float* a_base = As(cur) + (wm * TM * 32 + li) * LDSP + kh * 4;
+    const float* b_base = Bs(cur) + (wn * TN * 32 + li) * LDSP + kh * 4;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      f32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const f32x4*>(a_base + a * 32 * LDSP + kk * 8);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) fb[b] = *reinterpret_cast<const f32x4*>(b_base + b * 32 * LDSP + kk * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][e], fb[b][e], acc[a][b], 0, 0, 0);
+    }
+    if (t + 1 < nk) {
+      store_tile<C_::BM, C_::kALoads, C_::kThreads>(As(cur ^ 1), ra);
+      store_tile<C_::BN, C_::kBLoads, C_::kThreads>(Bs(cur ^ 1), rb);
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  switch (g.group) {
+    case 1: epilogue<WM, WN, TM, TN, 1>(g, acc, m0, n0, wm, wn, li, kh); break;
+    case 2: epilogue<WM, WN, TM, TN, 2>(g, acc, m0, n0, wm, wn, li, kh); break;
+    default: epilogue<WM, WN, TM, TN, 4>(g, acc, m0, n0, wm, wn, li, kh); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dW[N,K] = sum_r Z[r,N]^T A[r,K]   (split over r into `splits` slabs, reduced below)
+constexpr int TBR = 16;          // rows (reduction) per tile step
+constexpr int TLD = 128 + 4;     // LDS pitch for the [32][128] images
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(sr_gemm_tn_args g, int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) float Zs[2][TBR * TLD];
+  __shared__ __attribute__((aligned(16))) float Xs[2][TBR * TLD];
+  const int tiles_k = (g.K + 127) / 128;
+  const int tiles_n = (g.N + 127) / 128;
+  const int tile = blockIdx.x % (tiles_k * tiles_n), split = blockIdx.x / (tiles_k * tiles_n);
+  const int n0 = (tile / tiles_k) * 128, k0 = (tile % tiles_k) * 128;
+  const int r_begin = split * rows_per_split;
+  const int r_end = min(g.R, r_begin + rows_per_split);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kh = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // each thread moves 4 float4 of Z and 4 of A per step: tile [32 rows][128 cols] = 1024 float4
+  f32x4 rz[4], rx[4];
+  auto load = [&](int r0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = threadIdx.x + j * 256;
+      const int row = idx >> 5, cq = idx & 31;
+      const int gr = r0 + row;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f}, x = {0.f, 0.f, 0.f, 0.f};
+      if (gr < r_end) {
+        const int cn = n0 + cq * 4, ck = k0 + cq * 4;
+        if (cn < g.N) {
+          z = *reinterpret_cast<const f32x4*>(g.Z + (int64_t)gr * g.ldz + cn);
+          if (cn + 1 >= g.N) z.y = 0.f;
+          if (cn + 2 >= g.N) z.z = 0.f;
+          if (cn + 3 >= g.N) z.w = 0.f;
+        }
+        if (ck < g.K) {
+          x = *reinterpret_cast<const f32x4*>(g.A + (int64_t)gr * g.lda + ck);
+          if (ck + 1 >= g.K) x.y = 0.f;
+          if (ck + 2 >= g.K) x.z = 0.f;
+          if (ck + 3 >= g.K) x.w = 0.f;
+        }
+      }
+      rz[j] = z; rx[j] = x;
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = threadIdx.x + j * 256;
+      const int row = idx >> 5, cq = idx & 31;
+      *reinterpret_cast<f32x4*>(&Zs[buf][row * TLD + cq * 4]) = rz[j];
+      *reinterpret_cast<f32x4*>(&Xs[buf][row * TLD + cq * 4]) = rx[j];
+    }
+  };
+
+  const int nsteps = (r_end - r_begin + TBR - 1) / TBR;
+  if (nsteps > 0) {
+    load(r_begin);
+    store(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < nsteps; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nsteps) load(r_begin + (t + 1) * TBR);
+    const float* zb = &Zs[cur][kh * TLD + wm * 64 + li];
+    const float* xb = &Xs[cur][kh * TLD + wn * 64 + li];
+#pragma unroll
+    for (int e = 0; e < TBR / 2; ++e) {  // rows 2e + kh
+      const float z0 = zb[2 * e * TLD], z1 = zb[2 * e * TLD + 32];
+      const float x0 = xb[2 * e * TLD], x1 = xb[2 * e * TLD + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0, x0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0, x1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1, x0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1, x1, acc[1][1], 0, 0, 0);
+    }
+    if (t + 1 < nsteps) store(cur ^ 1);
+    __syncthreads();
+  }
+  float* out = g.partial + (int64_t)split * g.N * g.lddw;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int col = k0 + wn * 64 + b * 32 + li;
+      if (col >= g.K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = n0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < g.N) out[(int64_t)row * g.lddw + col] = acc[a][b][r];
+      }
+    }
+}
+
+// dW = (accumulate ? dW : 0) + sum_s partial[s]; padding columns [K, lddw) are written as 0.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int N,
+                                                           int K, int64_t lddw, int splits, int accumulate) {
+  const int64_t total = (int64_t)N * lddw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % lddw);
+    float s = 0.f;
+    if (col < K)
+      for (int p = 0; p < splits; ++p) s += partial[(int64_t)p * total + i];
+    dW[i] = (accumulate ? dW[i] : 0.f) + s;
+  }
+}
+
+// out[n] = sum over primal rows (r % group == 0) of Z[r][n]; one workgroup per 64 columns x row-slice,
+// finished by atomics into a zeroed `out` only when more than one slice exists.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Z, int64_t ldz, int R, int N, int group,
+                                                      float* __restrict__ out, int rows_per_block) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;
+  const int r_begin = blockIdx.y * rows_per_block;
+  const int r_end = min(R, r_begin + rows_per_block);
+  float s = 0.f;
+  if (c < N)
+    for (int r = r_begin + sub * group; r < r_end; r += 4 * group) s += Z[(int64_t)r * ldz + c];
+  red[sub][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sub == 0 && c < N) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
+  if (!a || !a->A || !a->B || !a->C || a->M < 0 || a->N <= 0 || a->K <= 0) return SR_EINVAL;
+  if (a->group != 1 && a->group != 2 && a->group != 4) return SR_EINVAL;
+  if ((a->lda & 3) || (a->ldb & 3) || ((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15)) return SR_EINVAL;
+  if (a->mode != SR_EPI_FWD && a->mode != SR_EPI_BWD) return SR_EINVAL;
+  if ((a->naux_fwd > 0 || a->mode == SR_EPI_BWD) && a->act != SR_ACT_NONE && !a->aux && a->mode == SR_EPI_BWD) return SR_EINVAL;
+  if (a->mode == SR_EPI_FWD && a->naux_fwd > 0 && !a->aux) return SR_EINVAL;
+  if (a->M == 0) return SR_OK;
+  if (a->M % a->group) return SR_EINVAL;
+  const int ncols = a->N + (a->mode == SR_EPI_FWD ? a->naux_fwd : 0);
+  sr_gemm_args g = *a;
+  if (g.mode != SR_EPI_FWD) g.naux_fwd = 0;
+  if (ncols <= 32) {
+    using C_ = Cfg<4, 1, 2, 1>;
+    const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));
+    hipLaunchKernelGGL((gemm_nt_kernel<4, 1, 2, 1>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), (hipStream_t)stream, g);
+  } else {
+    using C_ = Cfg<2, 2, 2, 2>;
+    const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));
+    hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), (hipStream_t)stream, g);
+  }
+  return sr_launch_status();
+}
+
+int64_t sr_mlp_gemm_tn_workspace_floats(int32_t R, int32_t N, int64_t lddw, int32_t* splits_out) {
+  const int tiles = (int)(sr_cdiv(N, 128) * sr_cdiv(lddw, 128));
+  int splits = (int)sr_cdiv(1024, tiles);            // aim at ~4 workgroups per CU
+  const int max_splits = (int)sr_cdiv(R, 256);       // at least 256 rows per split
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  if (splits_out) *splits_out = splits;
+  return (int64_t)splits * N * lddw;
+}
+
+int sr_mlp_gemm_tn(const sr_gemm_tn_args* a, void* stream) {
+  if (!a || !a->Z || !a->A || !a->dW || !a->partial || a->R < 0 || a->N <= 0 || a->K <= 0 || a->splits < 1) return SR_EINVAL;
+  if ((a->ldz & 3) || (a->lda & 3) || ((uintptr_t)a->Z & 15) || ((uintptr_t)a->A & 15) || a->lddw < a->K) return SR_EINVAL;
+  const int tiles = (int)(sr_cdiv(a->N, 128) * sr_cdiv(a->K, 128));
+  int rows_per_split = (int)sr_cdiv(a->R, a->splits);
+  rows_per_split = (int)(sr_cdiv(rows_per_split, TBR) * TBR);
+  if (a->R > 0)
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * a->splits), dim3(256), 0, (hipStream_t)stream, *a, rows_per_split);
+  const int64_t total = (int64_t)a->N * a->lddw;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(sr_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, a->partial, a->dW,
+                     a->N, a->K, a->lddw, a->R > 0 ? a->splits : 0, a->accumulate);
+  return sr_launch_status();
+}
+
+int sr_colsum_rows(const float* Z, int64_t ldz, int32_t R, int32_t N, int32_t group, float* out, void* stream) {
+  if (!Z || !out || R < 0 || N <= 0 || group < 1) return SR_EINVAL;
+  if (R == 0) return SR_OK;
+  int slices = (int)sr_cdiv(R, 4096);
+  if (slices > 256) slices = 256;
+  int rows_per_block = (int)sr_cdiv(R, slices);
+  rows_per_block = (int)(sr_cdiv(rows_per_block, 4 * group) * 4 * group);
+  slices = (int)sr_cdiv(R, rows_per_block);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sr_cdiv(N, 64), slices), dim3(256), 0, (hipStream_t)stream, Z, ldz, R, N, group, out, rows_per_block);
+  return sr_launch_status();
+}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Positional encoding + feature concatenation -> first-layer input rows (a1).
+// out[row, :] = [x(3) | w_k sin(2^k x), w_k cos(2^k x) (k<L) | extra(E) | 0 pad] following
+// model/Embedder.py:9-41 (band order, 3-wide blocks) and utils/utils.py:40-46 (weights come in
+// pairs).  With group == 4 the 3 rows after each primal row receive d/dx_t of that embedding
+// (t = 0,1,2) -- the seed tangents of the forward-mode Jacobian -- and zeros under `extra`.
+namespace {
+__global__ __launch_bounds__(256) void pe_embed_kernel(const float* __restrict__ x, int64_t P, int L, const float* __restrict__ w,
+                                                        const float* __restrict__ extra, int64_t ldextra, int E,
+                                                        const int64_t* __restrict__ extra_index, int group,
+                                                        float* __restrict__ out, int64_t ldo) {
+  const int width = 3 + 6 * L + E;
+  const int64_t total = P * ldo;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / ldo;
+    const int c = (int)(i % ldo);
+    float v = 0.f, t3[3] = {0.f, 0.f, 0.f};
+    if (c < 3) {
+      v = x[p * 3 + c];
+      t3[c] = 1.f;
+    } else if (c < 3 + 6 * L) {
+      const int k = (c - 3) / 6, r = (c - 3) % 6, comp = r % 3;
+      const float f = (float)(1 << k);
+      const float a = x[p * 3 + comp] * f;
+      const float wk = w[2 * k + (r >= 3)];
+      if (r < 3) { v = wk * sinf(a); t3[comp] = wk * f * cosf(a); }
+      else { v = wk * cosf(a); t3[comp] = -wk * f * sinf(a); }
+    } else if (c < width) {
+      const int64_t src = extra_index ? extra_index[p] : p;
+      v = extra[src * ldextra + (c - 3 - 6 * L)];
+    }
+    out[(p * group) * ldo + c] = v;
+    if (group == 4) {
+      out[(p * 4 + 1) * ldo + c] = t3[0];
+      out[(p * 4 + 2) * ldo + c] = t3[1];
+      out[(p * 4 + 3) * ldo + c] = t3[2];
+    }
+  }
+}
+}  // namespace
+
+extern "C" int sr_pe_embed(const float* x, int64_t P, int32_t L, const float* band_weights, const float* extra, int64_t ldextra,
+                           int32_t E, const int64_t* extra_index, int32_t group, float* out, int64_t ldo, void* stream) {
+  if (P < 0 || L < 0 || L > 16 || E < 0 || (group != 1 && group != 4) || ldo < 3 + 6 * L + E) return SR_EINVAL;
+  if (P == 0) return SR_OK;
+  if (!x || !out || (L > 0 && !band_weights) || (E > 0 && !extra)) return SR_EINVAL;
+  hipLaunchKernelGGL(pe_embed_kernel, dim3(sr_stream_grid(P * ldo, 256)), dim3(256), 0, (hipStream_t)stream, x, P, L, band_weights,
+                     extra, ldextra, E, extra_index, group, out, ldo);
+  return sr_launch_status();
+}

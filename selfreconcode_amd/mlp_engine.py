@@ -1,0 +1,257 @@
+"""Host side of the fused MLP engine: drives the fp32-MFMA layer kernels of csrc/mlp_gemm.hip.
+
+One engine serves the three networks of the hot path (SDF a2/a3, deformer a4, render a10) and
+all the derivative orders the reference reaches through autograd:
+
+  * rows are tangent-interleaved: a sample owns `group` rows = primal + (group-1) forward tangents;
+  * `forward(A0, ..., group)` runs the layers (activations, skip concat, tangent propagation fused
+    in the GEMM epilogues) and keeps the stored activations;
+  * `reverse(...)` is ONE reverse sweep over that (augmented) network: cotangents of the
+    pre-activations, the weight/bias gradients and the input cotangent.
+
+`MLPCoreFunction` wraps it for torch autograd to second order:
+    y = MLP(A0; W, b)                    forward            (group 1)
+    (dA0, dW, db) = backward(ybar)       reverse            (group 1)
+    double backward with cotangent U on dA0:  S = <ybar, J_A0 U> is the forward tangent of y along U,
+    so its gradients are one group-2 forward + one group-2 reverse (reverse-over-reverse == reverse
+    over a 1-tangent forward).  Cotangents on dW/db (third-party code differentiating parameter
+    gradients) are not supported -- the reference never does that.
+"""
+import math
+import ctypes
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_SOFTPLUS100, ACT_RELU = 0, 1, 2
+EPI_FWD, EPI_BWD = 0, 1
+
+
+def pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class LayerSpec:
+    __slots__ = ("K", "N", "act", "out_scale", "nfill")
+
+    def __init__(self, K, N, act, out_scale=1.0, nfill=0):
+        self.K, self.N, self.act, self.out_scale, self.nfill = K, N, act, float(out_scale), nfill
+
+
+class MLPSpec:
+    """Static description of one MLP: per layer (in, out, activation), optional skip concat:
+    the layer BEFORE the skip writes [act(z) | A0[:, :nfill]] * out_scale (network.py:88-89)."""
+
+    def __init__(self, layers, K0):
+        self.layers = layers
+        self.K0 = K0
+
+    @staticmethod
+    def sdf(multires=6, width=512, nlin=9, skip_in=(4,), d_out=257):
+        K0 = 3 + 6 * multires
+        layers = []
+        k = K0
+        for l in range(nlin):
+            last = l == nlin - 1
+            n = d_out if last else width
+            if (l + 1) in skip_in:
+                layers.append(LayerSpec(k, n - K0, ACT_SOFTPLUS100, 1.0 / math.sqrt(2.0), nfill=K0))
+            else:
+                layers.append(LayerSpec(k, n, ACT_NONE if last else ACT_SOFTPLUS100))
+            k = n
+        return MLPSpec(layers, K0)
+
+    @staticmethod
+    def relu_mlp(K0, widths):
+        layers, k = [], K0
+        for i, n in enumerate(widths):
+            layers.append(LayerSpec(k, n, ACT_NONE if i == len(widths) - 1 else ACT_RELU))
+            k = n
+        return MLPSpec(layers, K0)
+
+
+def _gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, group, act, mode, out_scale=1.0, aux=None, ldaux=0, naux_fwd=0,
+             nact_bwd=0, aux_scale=1.0):
+    a = _lib.SrGemmArgs()
+    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = _lib.ptr(A), lda, _lib.ptr(B), ldb, _lib.ptr(C), ldc
+    a.M, a.N, a.K = M, N, K
+    a.bias = _lib.ptr(bias)
+    a.group, a.act, a.mode, a.out_scale = group, act, mode, out_scale
+    a.aux, a.ldaux, a.naux_fwd, a.nact_bwd, a.aux_scale = _lib.ptr(aux), ldaux, naux_fwd, nact_bwd, aux_scale
+    _lib.call("sr_mlp_gemm_nt", ctypes.byref(a), _lib.stream_of(C))
+
+
+def _gemm_tn(Z, ldz, A, lda, R, N, K, lddw):
+    """dW [N, lddw] = Z[:, :N]^T A[:, :K] (deterministic slab reduction)."""
+    splits = ctypes.c_int32(0)
+    ws = _lib.raw("sr_mlp_gemm_tn_workspace_floats")(R, N, lddw, ctypes.byref(splits))
+    dW = torch.empty((N, lddw), dtype=torch.float32, device=Z.device)
+    partial = torch.empty((max(int(ws), 1),), dtype=torch.float32, device=Z.device)
+    a = _lib.SrGemmTnArgs()
+    a.Z, a.ldz, a.A, a.lda, a.dW, a.lddw, a.partial = _lib.ptr(Z), ldz, _lib.ptr(A), lda, _lib.ptr(dW), lddw, _lib.ptr(partial)
+    a.R, a.N, a.K, a.splits, a.accumulate = R, N, K, splits.value, 0
+    _lib.call("sr_mlp_gemm_tn", ctypes.byref(a), _lib.stream_of(Z))
+    return dW
+
+
+def _colsum(Z, ldz, R, N, group):
+    out = torch.zeros((N,), dtype=torch.float32, device=Z.device)
+    _lib.call("sr_colsum_rows", _lib.ptr(Z), ldz, R, N, group, _lib.ptr(out), _lib.stream_of(Z))
+    return out
+
+
+def _check_mat(t, name):
+    if t.dtype != torch.float32 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1 or (t.stride(0) % 4) or (t.data_ptr() % 16):
+        raise RuntimeError(f"mlp_engine: {name} must be a GPU fp32 matrix with unit column stride, row pitch % 4 == 0 "
+                           f"and 16-byte alignment (got {tuple(t.shape)}, strides {t.stride()}, {t.dtype}, {t.device})")
+
+
+def forward(spec, A0, Ws, bs, group):
+    """A0 [R, >=K0] (pitch % 4 == 0); Ws[l] [N_l, pad4(K_l)]; returns the stored activations per layer
+    (each [R, pad4(N_l + nfill_l)]); the last one holds the network output in its first N_L columns."""
+    _check_mat(A0, "A0")
+    R = A0.shape[0]
+    acts, X = [], A0
+    with torch.cuda.device(A0.device):
+        for l, L in enumerate(spec.layers):
+            _check_mat(Ws[l], f"W{l}")
+            C = torch.empty((R, pad4(L.N + L.nfill)), dtype=torch.float32, device=A0.device)
+            _gemm_nt(X, X.stride(0), Ws[l], Ws[l].stride(0), C, C.stride(0), R, L.N, L.K, bs[l], group, L.act, EPI_FWD,
+                     out_scale=L.out_scale, aux=A0 if L.nfill else None, ldaux=A0.stride(0), naux_fwd=L.nfill)
+            acts.append(C)
+            X = C
+    return acts
+
+
+def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_grad=True):
+    """One reverse sweep.  Ybar [R, >= N_L] (pitch % 4): cotangent of the output rows.  WTs[l] = W_l^T as
+    [K_l, pad4(N_l)].  Returns (A0bar [R, pad4(K0)] or None, dWs [N_l, pad4(K_l)], dbs [N_l])."""
+    _check_mat(Ybar, "Ybar")
+    R = A0.shape[0]
+    nl = len(spec.layers)
+    dWs, dbs = [None] * nl, [None] * nl
+    A0bar_extra = None
+    Zbar = Ybar
+    A0bar = None
+    with torch.cuda.device(A0.device):
+        for l in range(nl - 1, -1, -1):
+            L = spec.layers[l]
+            X = A0 if l == 0 else acts[l - 1]
+            if need_param_grad:
+                dWs[l] = _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K))
+                dbs[l] = _colsum(Zbar, Zbar.stride(0), R, L.N, group)
+            if l > 0:
+                Pv = spec.layers[l - 1]
+                Znew = torch.empty((R, pad4(L.K)), dtype=torch.float32, device=A0.device)
+                _gemm_nt(Zbar, Zbar.stride(0), WTs[l], WTs[l].stride(0), Znew, Znew.stride(0), R, L.K, L.N, None, group, Pv.act,
+                         EPI_BWD, out_scale=Pv.out_scale, aux=acts[l - 1], ldaux=acts[l - 1].stride(0), nact_bwd=Pv.N,
+                         aux_scale=Pv.out_scale)
+                if Pv.nfill and need_input_grad:
+                    A0bar_extra = Znew[:, Pv.N:Pv.N + Pv.nfill]
+                Zbar = Znew
+            elif need_input_grad:
+                A0bar = torch.empty((R, pad4(L.K)), dtype=torch.float32, device=A0.device)
+                _gemm_nt(Zbar, Zbar.stride(0), WTs[0], WTs[0].stride(0), A0bar, A0bar.stride(0), R, L.K, L.N, None, 1, ACT_NONE,
+                         EPI_FWD)
+                if A0bar_extra is not None:
+                    A0bar[:, :A0bar_extra.shape[1]] += A0bar_extra
+    return A0bar, dWs, dbs
+
+
+def transpose_padded(W, K):
+    """W [N, pad4(K)] -> W^T as [K, pad4(N)] (zero padded)."""
+    N = W.shape[0]
+    WT = torch.zeros((K, pad4(N)), dtype=W.dtype, device=W.device)
+    WT[:, :N] = W[:, :K].t()
+    return WT
+
+
+def pad_cols(t, width):
+    if t.shape[1] == width and t.is_contiguous():
+        return t
+    return torch.nn.functional.pad(t, (0, width - t.shape[1]))
+
+
+def interleave(rows):
+    """[R,K] x g -> [g*R, K] with sample-major interleaving (primal, tangent_1, ...)."""
+    return torch.stack(rows, dim=1).reshape(rows[0].shape[0] * len(rows), rows[0].shape[1])
+
+
+class MLPCoreFunction(torch.autograd.Function):
+    """y[P, N_L] = MLP(A0[P, pad4(K0)]; W_l [N_l, pad4(K_l)], b_l)."""
+
+    @staticmethod
+    def forward(ctx, spec, A0, *wb):
+        nl = len(spec.layers)
+        Ws, bs = list(wb[:nl]), list(wb[nl:])
+        acts = forward(spec, A0, Ws, bs, 1)
+        ctx.spec = spec
+        ctx.save_for_backward(A0, *wb, *acts[:-1])
+        ctx.set_materialize_grads(False)
+        NL = spec.layers[-1].N
+        out = acts[-1]
+        return out if out.shape[1] == NL else out[:, :NL]
+
+    @staticmethod
+    def backward(ctx, ybar):
+        if ybar is None:
+            return (None,) * (2 + 2 * len(ctx.spec.layers))
+        saved = ctx.saved_tensors
+        nl = len(ctx.spec.layers)
+        A0, wb, acts = saved[0], saved[1:1 + 2 * nl], saved[1 + 2 * nl:]
+        outs = MLPCoreBackward.apply(ctx.spec, ctx.needs_input_grad[1], any(ctx.needs_input_grad[2:]), A0, ybar, *wb, *acts)
+        return (None,) + tuple(outs)
+
+
+class MLPCoreBackward(torch.autograd.Function):
+    """(A0bar, dW_0.., db_0..) = reverse sweep; itself differentiable w.r.t. (A0, ybar, W, b) for a
+    cotangent on A0bar (see module docstring)."""
+
+    @staticmethod
+    def forward(ctx, spec, need_in, need_par, A0, ybar, *rest):
+        nl = len(spec.layers)
+        Ws, bs, acts = list(rest[:nl]), list(rest[nl:2 * nl]), list(rest[2 * nl:])
+        NL = spec.layers[-1].N
+        yb = pad_cols(ybar, pad4(NL))
+        WTs = [transpose_padded(Ws[l], spec.layers[l].K) for l in range(nl)]
+        A0bar, dWs, dbs = reverse(spec, A0, WTs, acts, yb, 1, need_in, need_par)
+        ctx.spec = spec
+        ctx.save_for_backward(A0, ybar, *Ws, *bs)
+        ctx.set_materialize_grads(False)
+        if A0bar is not None and A0bar.shape[1] != A0.shape[1]:
+            A0bar = pad_cols(A0bar[:, :spec.K0], A0.shape[1])
+        return (A0bar,) + tuple(dWs) + tuple(dbs)
+
+    @staticmethod
+    def backward(ctx, U, *param_cots):
+        spec = ctx.spec
+        nl = len(spec.layers)
+        if any(c is not None for c in param_cots):
+            raise NotImplementedError("selfreconcode_amd: differentiating MLP parameter gradients again is not supported "
+                                      "(the reference only differentiates input gradients, network.py:102-114)")
+        n_in = 5 + 2 * nl + (nl - 1)
+        if U is None:
+            return (None,) * n_in
+        saved = ctx.saved_tensors
+        A0, ybar = saved[0], saved[1]
+        Ws, bs = list(saved[2:2 + nl]), list(saved[2 + nl:2 + 2 * nl])
+        NL = spec.layers[-1].N
+        R = A0.shape[0]
+        # group-2 augmented forward: rows (a0, U)
+        A0i = interleave([A0, pad_cols(U, A0.shape[1])])
+        acts2 = forward(spec, A0i, Ws, bs, 2)
+        ydot = acts2[-1].view(R, 2, -1)[:, 1, :NL]                     # d S / d ybar
+        yb = pad_cols(ybar, pad4(NL))
+        ybi = interleave([torch.zeros_like(yb), yb])                    # cotangent only on the tangent output
+        WTs = [transpose_padded(Ws[l], spec.layers[l].K) for l in range(nl)]
+        need_in = ctx.needs_input_grad[3]
+        need_par = any(ctx.needs_input_grad[5:5 + 2 * nl])
+        A0bar2, dWs, dbs = reverse(spec, A0i, WTs, acts2, ybi, 2, need_in, need_par)
+        gA0 = A0bar2.view(R, 2, -1)[:, 0, :] if A0bar2 is not None else None
+        if gA0 is not None and gA0.shape[1] != A0.shape[1]:
+            gA0 = pad_cols(gA0[:, :spec.K0], A0.shape[1])
+        return (None, None, None, gA0, ydot.contiguous()) + tuple(dWs) + tuple(dbs) + (None,) * (nl - 1)
+
+
+def mlp_apply(spec, A0, Ws, bs):
+    return MLPCoreFunction.apply(spec, A0, *Ws, *bs)

@@ -1,0 +1,96 @@
+"""Positional encoding -- mirrors model/Embedder.py:4-54 (get_embedder / Embedder.embed) on the fused
+HIP embed kernel.  Band order [x | sin f0 | cos f0 | sin f1 | ...], bands 2^k, per-band weights
+in (sin, cos) pairs from utils.annealing_weights (utils/utils.py:40-46)."""
+import torch
+from .. import _lib
+from ..mlp_engine import pad4
+
+_WCACHE = {}
+
+
+def band_weight_tensor(ws, multires, device):
+    """2*L floats on the device; cached per (weights, device) -- no per-call H2D traffic."""
+    if ws is None:
+        ws = (1.0,) * (2 * multires)
+    key = (tuple(float(w) for w in ws), str(device))
+    t = _WCACHE.get(key)
+    if t is None:
+        t = torch.tensor(key[0], dtype=torch.float32, device=device)
+        _WCACHE[key] = t
+    return t, key[0]
+
+
+class PEFunction(torch.autograd.Function):
+    """A0[P, pad4(3+6L+E)] = [x | PE_L(x) | extra[index] | 0].  The backward is written with
+    differentiable torch ops on the saved OUTPUT (d sin = f cos, d cos = -f sin are again columns
+    of A0), so any derivative order works."""
+
+    @staticmethod
+    def forward(ctx, x, wt, L, extra, extra_index):
+        _lib.require_gpu(x)
+        x = x.contiguous().float()
+        P = x.shape[0]
+        E = 0 if extra is None else extra.shape[1]
+        ldo = pad4(3 + 6 * L + E)
+        out = torch.empty((P, ldo), dtype=torch.float32, device=x.device)
+        ex = None if extra is None else extra.contiguous().float()
+        with torch.cuda.device(x.device):
+            _lib.call("sr_pe_embed", _lib.ptr(x), P, L, _lib.ptr(wt), _lib.ptr(ex), 0 if ex is None else ex.stride(0), E,
+                      _lib.ptr(extra_index), 1, _lib.ptr(out), ldo, _lib.stream_of(x))
+        ctx.L, ctx.E = L, E
+        ctx.n_extra = 0 if extra is None else extra.shape[0]
+        ctx.save_for_backward(out, extra_index)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, extra_index = ctx.saved_tensors
+        L, E = ctx.L, ctx.E
+        P = out.shape[0]
+        gx = g[:, :3]
+        if L > 0:
+            Eb = out[:, 3:3 + 6 * L].reshape(P, L, 2, 3)
+            gb = g[:, 3:3 + 6 * L].reshape(P, L, 2, 3)
+            f = (2.0 ** torch.arange(L, device=out.device, dtype=out.dtype)).view(1, L, 1)
+            gx = gx + ((Eb[:, :, 1] * gb[:, :, 0] - Eb[:, :, 0] * gb[:, :, 1]) * f).sum(1)
+        gextra = None
+        if E > 0 and ctx.needs_input_grad[3]:
+            ge = g[:, 3 + 6 * L:3 + 6 * L + E]
+            if extra_index is None:
+                gextra = ge
+            else:
+                gextra = torch.zeros((ctx.n_extra, E), dtype=g.dtype, device=g.device).index_add(0, extra_index, ge)
+        return gx, None, None, gextra, None
+
+
+def embed_rows(x, multires, ws=None, extra=None, extra_index=None):
+    """First-layer input rows [P, pad4(3 + 6*multires + E)] (fused PE + concat)."""
+    if ws is not None and any(float(ws[2 * k]) != float(ws[2 * k + 1]) for k in range(multires)):
+        raise NotImplementedError("fused embedder needs equal (sin, cos) weights per band, as utils.annealing_weights yields")
+    wt, _ = band_weight_tensor(ws, multires, x.device)
+    return PEFunction.apply(x, wt, multires, extra, extra_index)
+
+
+class Embedder:
+    """API mirror of the reference class (kwargs, out_dim, embed(inputs, ws))."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+        assert kwargs['include_input'] and kwargs['input_dims'] == 3 and kwargs['log_sampling']
+        assert kwargs['max_freq_log2'] == kwargs['num_freqs'] - 1
+        self.multires = kwargs['num_freqs']
+        self.out_dim = 3 + 6 * self.multires
+
+    def embed(self, inputs, ws=None):
+        shp = inputs.shape
+        out = embed_rows(inputs.reshape(-1, 3), self.multires, ws)[:, :self.out_dim]
+        return out.reshape(*shp[:-1], self.out_dim)
+
+
+def get_embedder(multires):
+    embedder_obj = Embedder(include_input=True, input_dims=3, max_freq_log2=multires - 1, num_freqs=multires,
+                            log_sampling=True, periodic_fns=[torch.sin, torch.cos])
+
+    def embed(x, ws=None, eo=embedder_obj):
+        return eo.embed(x, ws)
+    return embed, embedder_obj.out_dim

@@ -1,0 +1,158 @@
+"""Math half of the reference's utils/utils.py over the HIP ops."""
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from ..ext.FastMinv import Fast3x3Minv, Fast3x3Minv_backward
+
+
+class FastDiff3x3MinvFunction(Function):
+    """utils/utils.py:8-19."""
+
+    @staticmethod
+    def forward(ctx, input):
+        invs, check = Fast3x3Minv(input.contiguous())
+        ctx.save_for_backward(invs, check)
+        ctx.mark_non_differentiable(check)
+        return invs, check
+
+    @staticmethod
+    def backward(ctx, grad_input, grad_check):
+        invs, check = ctx.saved_tensors
+        return Fast3x3Minv_backward(grad_input.contiguous(), invs), None
+
+
+def annealing_weights(multires, ratio):
+    """utils/utils.py:40-46."""
+    alpha = ratio * multires
+    out = []
+    for ind in range(multires):
+        w = (1. - np.cos(np.pi * min(max(alpha - float(ind), 0.), 1.))) / 2.
+        out.extend([w, w])
+    return out
+
+
+def resolve_band_weights(multires, ratio):
+    """The None / <=0 / annealed switch shared by the three networks (network.py:74-80,
+    Deformer.py:51-57, RenderNet.py:56-62).  Returns None for 'all ones'."""
+    if ratio is None:
+        return None
+    if ratio <= 0:
+        return [0. for _ in range(multires * 2)]
+    return annealing_weights(multires, ratio)
+
+
+def GMRobustError(x, c, square=False):
+    """utils/utils.py:48-52."""
+    if square:
+        return 2. * x / (c * c) / (x / (c * c) + 4)
+    return 2. * x * x / (c * c) / (x * x / (c * c) + 4)
+
+
+def quat2mat(quat):
+    """utils/utils.py:21-38."""
+    nq = quat / quat.norm(p=2, dim=1, keepdim=True)
+    w, x, y, z = nq[:, 0], nq[:, 1], nq[:, 2], nq[:, 3]
+    B = quat.size(0)
+    w2, x2, y2, z2 = w.pow(2), x.pow(2), y.pow(2), z.pow(2)
+    wx, wy, wz = w * x, w * y, w * z
+    xy, xz, yz = x * y, x * z, y * z
+    return torch.stack([w2 + x2 - y2 - z2, 2 * xy - 2 * wz, 2 * wy + 2 * xz,
+                        2 * wz + 2 * xy, w2 - x2 + y2 - z2, 2 * yz - 2 * wx,
+                        2 * xz - 2 * wy, 2 * wx + 2 * yz, w2 - x2 - y2 + z2], dim=1).view(B, 3, 3)
+
+
+def smpl_tmp_Apose(init_pose_type=0):
+    """utils/utils.py:56-72."""
+    pose = np.zeros((24, 3))
+    if init_pose_type == 0:
+        a, b = 10., 45.
+    elif init_pose_type == 1:
+        a, b = 7., 55.
+    else:
+        assert False
+    pose[1] = np.array([0, 0, a / 180. * np.pi])
+    pose[2] = np.array([0, 0, -a / 180. * np.pi])
+    pose[16] = np.array([0, 0, -b / 180. * np.pi])
+    pose[17] = np.array([0, 0, b / 180. * np.pi])
+    return pose.astype(np.float32)
+
+
+def sample_points(pc_input, global_sigma, local_sigma, ratio=6):
+    """utils/utils.py:74-84."""
+    sample_size, dim = pc_input.shape
+    sample_local = pc_input + (torch.randn_like(pc_input) * local_sigma)
+    if ratio > 0:
+        sample_global = (torch.rand(sample_size // ratio, dim, device=pc_input.device) * (global_sigma * 2)) - global_sigma
+        return torch.cat([sample_local, sample_global], dim=0)
+    return sample_local
+
+
+def compute_Jacobian(ps, ds, retain_graph, create_graph, allow_unused=False):
+    """utils/utils.py:106-120 -- three reverse passes (generic drop-in path; the fused step uses the
+    forward-mode group-4 kernels instead, see model/Deformer.py)."""
+    grad_d_p = []
+    grad_outputs = torch.ones_like(ds[..., 0])
+    for c in range(3):
+        rg = True if c < 2 else retain_graph
+        out = torch.autograd.grad(ds[..., c], ps, grad_outputs, retain_graph=rg, create_graph=create_graph, allow_unused=allow_unused)
+        grad_d_p.append(out[0].view(-1, 1, 3))
+    return torch.cat(grad_d_p, dim=1)
+
+
+def compute_deformed_normals(sdf, deformer, ps, defconds, batch_inds, ratio, phase):
+    """utils/utils.py:132-153."""
+    sdfs = sdf(ps, ratio)
+    check = phase in ('train', 'Train')
+    onx = torch.autograd.grad(sdfs, ps, torch.ones_like(sdfs), retain_graph=check, create_graph=check)[0]
+    ds = deformer(ps, defconds, batch_inds, ratio=ratio)
+    grad_d_p = compute_Jacobian(ps, ds, check, check)
+    grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
+    nx = grad_d_p_inv.transpose(-2, -1).matmul(onx.view(-1, 3, 1)).view(-1, 3)
+    n_inv_mask = ~inv_mask
+    if n_inv_mask.sum().item() > 0:
+        print('unwished error n_inv_mask:(%d:%d)' % (n_inv_mask.sum().item(), n_inv_mask.numel()))
+        nnx = torch.zeros_like(nx)
+        nnx[inv_mask] = nx[inv_mask]
+        nnx[n_inv_mask] = grad_d_p[n_inv_mask].matmul(onx[n_inv_mask].unsqueeze(-1)).view(-1, 3)
+        nx = nnx
+    nx = nx / nx.norm(dim=1, keepdim=True)
+    return nx, ds
+
+
+def compute_cardinal_rays(deformer, ps, rays, defconds, batch_inds, ratio, phase):
+    """utils/utils.py:155-169."""
+    check = phase in ('train', 'Train')
+    ds = deformer(ps, defconds, batch_inds, ratio=ratio)
+    grad_d_p = compute_Jacobian(ps, ds, check, check)
+    grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
+    crays = grad_d_p_inv.matmul(rays.view(-1, 3, 1)).view(-1, 3)
+    n_inv_mask = ~inv_mask
+    if n_inv_mask.sum().item() > 0:
+        print('unwished error n_inv_mask:(%d:%d)' % (n_inv_mask.sum().item(), n_inv_mask.numel()))
+        ncrays = torch.zeros_like(crays)
+        ncrays[inv_mask] = crays[inv_mask]
+        ncrays[n_inv_mask] = rays[n_inv_mask].detach()
+        crays = ncrays
+    crays = crays / crays.norm(dim=1, keepdim=True)
+    return crays, ds
+
+
+def compute_netRender_color(net, ps, ds, ns, vs, features, framefeatures, ratio):
+    """utils/utils.py:171-172 (framefeatures and ds are ignored by the reference as well)."""
+    return net(ps, ns, vs, features, ratio)
+
+
+def DCTBasis(k, N):
+    assert k < N
+    basis = torch.tensor([np.pi * (float(n) + 0.5) * k / float(N) for n in range(N)]).float()
+    return torch.cos(basis) * (1. / np.sqrt(float(N)) if k == 0 else np.sqrt(2. / float(N)))
+
+
+def DCTNullSpace(k, N):
+    """utils/utils.py:207-208."""
+    return torch.stack([DCTBasis(ind, N) for ind in range(k, N)])
+
+
+def DCTSpace(k, N):
+    return torch.stack([DCTBasis(ind, N) for ind in range(0, k)])

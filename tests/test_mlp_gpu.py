@@ -1,0 +1,168 @@
+"""GPU parity of the three MLP drop-ins (SDF a2/a3, deformer a4, render a10) and of the raw
+tangent-interleaved engine, against the reference-generated golden vectors and the CPU oracle.
+Tolerances: fp32 MFMA accumulates in a different order than the CPU GEMM -> values to 2e-5
+relative / 2e-6 absolute, first derivatives to 1e-4, second-order parameter gradients to 1e-3."""
+import pytest
+import torch
+from oracle import torch_oracle as orc
+from oracle import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RATIO = {'sdfRatio': 1.0, 'deformerRatio': 0.62, 'renderRatio': 1.0}
+
+
+def close(a, b, rtol=2e-5, atol=2e-6):
+    torch.testing.assert_close(a.detach().float().cpu(), b.detach().float().cpu(), rtol=rtol, atol=atol)
+
+
+def _sdf(seed=101):
+    from selfreconcode_amd.model.network import getTmpSdf
+    net = getTmpSdf(DEV, 6, 0.6, 256)
+    net.load_state_dict(fx.det_params(fx.SDF_SPEC, seed), strict=True)
+    return net
+
+
+def test_sdf_golden_forward_gradient_eikonal(golden):
+    g = golden("sdf")
+    net = _sdf()
+    for tag, ratio in [("r1", 1.0), ("r04", 0.4), ("dict", {'sdfRatio': 1.0, 'deformerRatio': 0.7, 'renderRatio': 1.0})]:
+        x = g["x"].to(DEV).requires_grad_(True)
+        y = net(x, ratio)
+        assert y.shape == (48, 1) and net.rendcond.shape == (48, 256)
+        gr = torch.autograd.grad(y, x, torch.ones_like(y), create_graph=True)[0]
+        close(y, g["sdf_" + tag]); close(net.rendcond[:, ::16], g["rend_" + tag])
+        close(gr, g["grad_" + tag], 1e-4, 1e-5)
+        if tag == "r1":
+            eik = ((gr.norm(2, dim=-1) - 1) ** 2).mean()
+            pg = torch.autograd.grad(eik, [net.lin0.weight_v, net.lin4.weight_g, net.lin7.bias, x])
+            close(eik, g["eik"], 1e-4)
+            close(pg[0][::37, ::5], g["eik_dv0"], 1e-3, 1e-5)
+            close(pg[1], g["eik_dg4"], 1e-3, 1e-5)
+            close(pg[2], g["eik_db7"], 1e-3, 1e-5)
+            close(pg[3], g["eik_dx"], 1e-3, 1e-5)
+
+
+@pytest.mark.parametrize("P", [1, 7, 129, 1000])
+def test_sdf_vs_oracle_ragged_sizes_and_param_grads(P):
+    net = _sdf(55)
+    sd = {k: v.clone().requires_grad_(True) for k, v in fx.det_params(fx.SDF_SPEC, 55).items()}
+    x = fx.det_tensor((P, 3), 900 + P, 0.9)
+    go = fx.det_tensor((P, 257), 901, 1.0)
+    xr = x.clone().requires_grad_(True)
+    yo, rc = orc.sdf_forward(sd, xr, 0.7)
+    lo = (torch.cat([yo, rc], 1) * go).sum()
+    ref = torch.autograd.grad(lo, [xr, sd["lin3.weight_v"], sd["lin3.weight_g"], sd["lin3.bias"], sd["lin8.weight_v"], sd["lin0.weight_v"]])
+    xg = x.to(DEV).requires_grad_(True)
+    y = net(xg, 0.7)
+    l = (torch.cat([y, net.rendcond], 1) * go.to(DEV)).sum()
+    ours = torch.autograd.grad(l, [xg, net.lin3.weight_v, net.lin3.weight_g, net.lin3.bias, net.lin8.weight_v, net.lin0.weight_v])
+    close(y, yo); close(net.rendcond, rc)
+    for a, b in zip(ours, ref):
+        close(a, b, 2e-4, 2e-5 * max(1.0, float(b.abs().max())))
+
+
+def test_sdf_empty_batch():
+    net = _sdf()
+    y = net(torch.zeros(0, 3, device=DEV), 1.0)
+    assert y.shape == (0, 1)
+
+
+def test_translator_golden(golden):
+    from selfreconcode_amd.model.Deformer import MLPTranslator
+    from selfreconcode_amd.utils import compute_Jacobian
+    g = golden("translator")
+    tr = MLPTranslator(128, 6).to(DEV)
+    tr.load_state_dict(fx.det_params(fx.DEF_SPEC, 202), strict=True)
+    y = tr(g["ps"].to(DEV), g["conds"].to(DEV), g["bi"].to(DEV), ratio=RATIO)
+    close(y, g["y"]); close(tr.offset, g["off"])
+    yb = tr(g["psb"].to(DEV), g["conds"].to(DEV), None, ratio=RATIO)
+    assert yb.shape == (3, 10, 3) and tr.offset.shape == (3, 10, 3)
+    close(yb, g["yb"])
+    p = g["ps"].to(DEV).requires_grad_(True)
+    d = tr(p, g["conds"].to(DEV), g["bi"].to(DEV), ratio=RATIO)
+    close(compute_Jacobian(p, d, True, True), g["J"], 1e-4, 1e-5)
+
+
+def test_translator_cond_and_second_order_grads():
+    """def-regu style: a loss on the Jacobian differentiated w.r.t. weights and per-frame codes."""
+    from selfreconcode_amd.model.Deformer import MLPTranslator
+    from selfreconcode_amd.utils import compute_Jacobian
+    tr = MLPTranslator(128, 6).to(DEV)
+    sd = fx.det_params(fx.DEF_SPEC, 7)
+    tr.load_state_dict(sd, strict=True)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ps = fx.det_tensor((37, 3), 1, 0.7); conds = fx.det_tensor((3, 128), 2, 0.1); bi = torch.arange(37) % 3
+    po = ps.clone().requires_grad_(True); co = conds.clone().requires_grad_(True)
+    do, _ = orc.translator_forward(sdo, po, co, bi, RATIO)
+    Jo = orc.compute_jacobian(po, do, True, True)
+    lo = (Jo ** 2).sum() + do.sum()
+    ref = torch.autograd.grad(lo, [po, co, sdo["lin1.weight"], sdo["lin0.weight"], sdo["lin4.bias"]], allow_unused=True)
+    pg = ps.to(DEV).requires_grad_(True); cg = conds.to(DEV).requires_grad_(True)
+    d = tr(pg, cg, bi.to(DEV), ratio=RATIO)
+    J = compute_Jacobian(pg, d, True, True)
+    l = (J ** 2).sum() + d.sum()
+    ours = torch.autograd.grad(l, [pg, cg, tr.lin1.weight, tr.lin0.weight, tr.lin4.bias], allow_unused=True)
+    close(J, Jo, 1e-4, 1e-5)
+    for a, b in zip(ours, ref):
+        close(a, b, 1e-3, 1e-4 * max(1.0, float(b.abs().max())))
+
+
+def test_render_golden_and_grads(golden):
+    from selfreconcode_amd.model.RenderNet import RenderingNetwork_view_norm
+    g = golden("render")
+    rn = RenderingNetwork_view_norm(256, 'idr', 9, 3, [512] * 4, True, multires_n=0, multires_v=4).to(DEV)
+    sd = fx.det_params(fx.REND_SPEC, 303)
+    rn.load_state_dict(sd, strict=True)
+    args = [g[k].to(DEV).requires_grad_(True) for k in ("pts", "nrm", "vd", "feat")]
+    col = rn(*args, RATIO)
+    close(col, g["col"])
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    argo = [g[k].clone().requires_grad_(True) for k in ("pts", "nrm", "vd", "feat")]
+    co = orc.render_forward(sdo, *argo, RATIO)
+    ref = torch.autograd.grad(co.abs().sum(), argo + [sdo["lin0.weight_v"], sdo["lin4.weight_g"]])
+    ours = torch.autograd.grad(col.abs().sum(), args + [rn.lin0.weight_v, rn.lin4.weight_g])
+    for a, b in zip(ours, ref):
+        close(a, b, 2e-4, 2e-5 * max(1.0, float(b.abs().max())))
+
+
+def test_engine_group4_tangents_and_reverse():
+    """forward-mode Jacobian rows (group 4) == autograd Jacobian of the oracle; the group-4 reverse
+    sweep == autograd gradient of a loss on (value, Jacobian)."""
+    from selfreconcode_amd import mlp_engine as me
+    from selfreconcode_amd import _lib
+    net = _sdf(9)
+    P = 50
+    x = fx.det_tensor((P, 3), 4, 0.8)
+    wt = torch.ones(12, device=DEV)
+    A0 = torch.empty((P * 4, 40), device=DEV)
+    xg = x.to(DEV)
+    _lib.call("sr_pe_embed", xg.data_ptr(), P, 6, wt.data_ptr(), 0, 0, 0, 0, 4, A0.data_ptr(), 40, 0)
+    Ws, bs = net.packed_weights()
+    Ws = [w.detach().contiguous() for w in Ws]; bs = [b.detach() for b in bs]
+    acts = me.forward(net.spec, A0, Ws, bs, 4)
+    out = acts[-1].view(P, 4, -1)[:, :, :257]
+    sd = {k: v.clone().requires_grad_(True) for k, v in fx.det_params(fx.SDF_SPEC, 9).items()}
+    xo = x.clone().requires_grad_(True)
+    yo, rc = orc.sdf_forward(sd, xo, None)
+    full = torch.cat([yo, rc], 1)
+    close(out[:, 0], full)
+    cols = [0, 1, 100, 256]
+    Jo = torch.stack([torch.autograd.grad(full[:, c].sum(), xo, retain_graph=True, create_graph=True)[0] for c in cols], 1)  # [P,4,3]
+    close(out[:, 1:, cols].permute(0, 2, 1), Jo, 1e-4, 1e-5)
+    # reverse sweep with cotangents on value and tangents of column 0
+    cy = fx.det_tensor((P,), 5, 1.0); cj = fx.det_tensor((P, 3), 6, 1.0)
+    lo = (yo[:, 0] * cy).sum() + (Jo[:, 0] * cj).sum()
+    ref = torch.autograd.grad(lo, [sd["lin2.weight_v"], sd["lin5.bias"], sd["lin0.weight_v"]])
+    ybar = torch.zeros((P, 4, 260), device=DEV)
+    ybar[:, 0, 0] = cy.to(DEV); ybar[:, 1:, 0] = cj.to(DEV)
+    WTs = [me.transpose_padded(Ws[l], net.spec.layers[l].K) for l in range(9)]
+    A0bar, dWs, dbs = me.reverse(net.spec, A0, WTs, acts, ybar.view(P * 4, 260), 4)
+    # chain dW_eff -> (g, v) through torch's own weight-norm autograd
+    v2 = net.lin2.weight_v.detach().clone().requires_grad_(True); g2 = net.lin2.weight_g.detach()
+    torch._weight_norm(v2, g2, 0).backward(dWs[2][:, :512])
+    close(v2.grad, ref[0], 1e-3, 1e-5)
+    close(dbs[5], ref[1], 1e-3, 1e-5)
+    v0 = net.lin0.weight_v.detach().clone().requires_grad_(True); g0 = net.lin0.weight_g.detach()
+    torch._weight_norm(v0, g0, 0).backward(dWs[0][:, :39])
+    close(v0.grad, ref[2], 1e-3, 1e-5)
