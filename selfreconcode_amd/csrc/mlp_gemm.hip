@@ -257,11 +257,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(sr_gemm_tn_args g, int row
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // each thread moves 4 float4 of Z and 4 of A per step: tile [32 rows][128 cols] = 1024 float4
-  f32x4 rz[4], rx[4];
+  // tile [TBR rows][128 cols] of Z and of A per step: TBR*32 float4 each, TLOADS per thread
+  constexpr int TLOADS = TBR * 32 / 256;
+  f32x4 rz[TLOADS], rx[TLOADS];
   auto load = [&](int r0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < TLOADS; ++j) {
       const int idx = threadIdx.x + j * 256;
       const int row = idx >> 5, cq = idx & 31;
       const int gr = r0 + row;
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(sr_gemm_tn_args g, int row
   };
   auto store = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < TLOADS; ++j) {
       const int idx = threadIdx.x + j * 256;
       const int row = idx >> 5, cq = idx & 31;
       *reinterpret_cast<f32x4*>(&Zs[buf][row * TLD + cq * 4]) = rz[j];
@@ -367,7 +368,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Z
 extern "C" {
 
 int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
-  if (!a || !a->A || !a->B || !a->C || a->M < 0 || a->N <= 0 || a->K <= 0) return SR_EINVAL;
+  if (!a || a->M < 0 || a->N <= 0 || a->K <= 0) return SR_EINVAL;
+  if (a->M == 0) return SR_OK;
+  if (!a->A || !a->B || !a->C) return SR_EINVAL;
   if (a->group != 1 && a->group != 2 && a->group != 4) return SR_EINVAL;
   if ((a->lda & 3) || (a->ldb & 3) || ((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15)) return SR_EINVAL;
   if (a->mode != SR_EPI_FWD && a->mode != SR_EPI_BWD) return SR_EINVAL;
@@ -401,7 +404,8 @@ int64_t sr_mlp_gemm_tn_workspace_floats(int32_t R, int32_t N, int64_t lddw, int3
 }
 
 int sr_mlp_gemm_tn(const sr_gemm_tn_args* a, void* stream) {
-  if (!a || !a->Z || !a->A || !a->dW || !a->partial || a->R < 0 || a->N <= 0 || a->K <= 0 || a->splits < 1) return SR_EINVAL;
+  if (!a || !a->dW || !a->partial || a->R < 0 || a->N <= 0 || a->K <= 0 || a->splits < 1) return SR_EINVAL;
+  if (a->R > 0 && (!a->Z || !a->A)) return SR_EINVAL;
   if ((a->ldz & 3) || (a->lda & 3) || ((uintptr_t)a->Z & 15) || ((uintptr_t)a->A & 15) || a->lddw < a->K) return SR_EINVAL;
   const int tiles = (int)(sr_cdiv(a->N, 128) * sr_cdiv(a->K, 128));
   int rows_per_split = (int)sr_cdiv(a->R, a->splits);
@@ -415,8 +419,9 @@ int sr_mlp_gemm_tn(const sr_gemm_tn_args* a, void* stream) {
 }
 
 int sr_colsum_rows(const float* Z, int64_t ldz, int32_t R, int32_t N, int32_t group, float* out, void* stream) {
-  if (!Z || !out || R < 0 || N <= 0 || group < 1) return SR_EINVAL;
+  if (!out || R < 0 || N <= 0 || group < 1) return SR_EINVAL;
   if (R == 0) return SR_OK;
+  if (!Z) return SR_EINVAL;
   int slices = (int)sr_cdiv(R, 4096);
   if (slices > 256) slices = 256;
   int rows_per_block = (int)sr_cdiv(R, slices);

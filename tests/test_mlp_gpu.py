@@ -161,8 +161,8 @@ def test_engine_group4_tangents_and_reverse():
     # chain dW_eff -> (g, v) through torch's own weight-norm autograd
     v2 = net.lin2.weight_v.detach().clone().requires_grad_(True); g2 = net.lin2.weight_g.detach()
     torch._weight_norm(v2, g2, 0).backward(dWs[2][:, :512])
-    close(v2.grad, ref[0], 1e-3, 1e-5)
-    close(dbs[5], ref[1], 1e-3, 1e-5)
+    close(v2.grad, ref[0], 1e-3, 1e-4 * float(ref[0].abs().max()))
+    close(dbs[5], ref[1], 1e-3, 1e-4 * float(ref[1].abs().max()))
     v0 = net.lin0.weight_v.detach().clone().requires_grad_(True); g0 = net.lin0.weight_g.detach()
     torch._weight_norm(v0, g0, 0).backward(dWs[0][:, :39])
-    close(v0.grad, ref[2], 1e-3, 1e-5)
+    close(v0.grad, ref[2], 1e-3, 1e-4 * float(ref[2].abs().max()))
