@@ -136,6 +136,44 @@ int sr_colsum_rows(const float* Z, int64_t ldz, int32_t R, int32_t N, int32_t gr
 int sr_pe_embed(const float* x, int64_t P, int32_t L, const float* band_weights, const float* extra, int64_t ldextra,
                 int32_t E, const int64_t* extra_index /*nullable*/, int32_t group, float* out, int64_t ldo, void* stream);
 
+/* ---------------------------------------------------------------- fused LBS (a5, a8/a9 LBS part)
+ * Replaces, for the no-autograd callers (ray refiner, inference), LBSkinner.forward's
+ * GridSamplerMine.forward + per-frame blend loop (model/Deformer.py:207-233) and, when `jac` is
+ * given, the three reverse passes of utils/utils.py:106-120 for the LBS factor of dd/dp.
+ * vol: skinning weights, channel-last [D,H,W,24] fp32, 16-byte aligned.  A: posed joint transforms
+ * (already times init_pose^-1) as [nframes,24,3,4] row-major.  Frame of point i = batch_inds[i], or
+ * i / points_per_frame when batch_inds == NULL.  tp (nullable): points used for the weight lookup when
+ * they differ from p (Deformer.py:168-171); jac requires tp == NULL. */
+typedef struct {
+  const float* p; const float* tp; int64_t P;
+  const float* A; const float* trans; int32_t nframes;
+  const int64_t* batch_inds; int64_t points_per_frame;
+  const float* vol; int32_t D, H, W;
+  float bmin[3], bmax[3];
+  float* y;        /* [P,3] */
+  float* jac;      /* [P,3,3] dy/dp, nullable */
+} sr_lbs_args;
+int sr_lbs_fwd(const sr_lbs_args* host_args, void* stream);
+
+/* ---------------------------------------------------------------- ray/surface refiner step (a12)
+ * One iteration body of utils/FindSurfacePs.py::OptimizeSurfacePs (:115-126 check, :135-151 step)
+ * for M live rays.  sdf4: output rows of the sdf-only SDF MLP, `group` rows per ray (row 0 = f,
+ * rows 1..3 = df/dp_t), pitch ld_sdf.  off4: output rows of the deformation MLP (row 0 = offset,
+ * rows 1..3 = d offset / d p_t), pitch ld_off.  y / jlbs: LBS output d(p) and dLBS/dq from sr_lbs_fwd.
+ * converged[i] = |f| < dthreshold && asin(|(d-c) x v| / |d-c|) * 180/pi < athreshold.
+ * group == 4 and p_out != NULL: p_out = converged ? p : p - L g / |g|^2.  group == 1: check only. */
+typedef struct {
+  int64_t M; int32_t group;
+  const float* sdf4; int64_t ld_sdf;
+  const float* off4; int64_t ld_off;
+  const float* y; const float* jlbs;
+  const float* rays; const float* cam;   /* [M,3], [3] (device) */
+  const float* p; float* p_out;          /* [M,3] */
+  uint8_t* converged;                    /* [M] */
+  float dthreshold, athreshold, w1, w2;
+} sr_newton_args;
+int sr_newton_update(const sr_newton_args* host_args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

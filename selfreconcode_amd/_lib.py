@@ -31,6 +31,18 @@ class SrGemmTnArgs(ctypes.Structure):
                 ("accumulate", ctypes.c_int32)]
 
 
+class SrLbsArgs(ctypes.Structure):
+    _fields_ = [("p", _vp), ("tp", _vp), ("P", _i64), ("A", _vp), ("trans", _vp), ("nframes", ctypes.c_int32),
+                ("batch_inds", _vp), ("points_per_frame", _i64), ("vol", _vp), ("D", ctypes.c_int32), ("H", ctypes.c_int32),
+                ("W", ctypes.c_int32), ("bmin", ctypes.c_float * 3), ("bmax", ctypes.c_float * 3), ("y", _vp), ("jac", _vp)]
+
+
+class SrNewtonArgs(ctypes.Structure):
+    _fields_ = [("M", _i64), ("group", ctypes.c_int32), ("sdf4", _vp), ("ld_sdf", _i64), ("off4", _vp), ("ld_off", _i64),
+                ("y", _vp), ("jlbs", _vp), ("rays", _vp), ("cam", _vp), ("p", _vp), ("p_out", _vp), ("converged", _vp),
+                ("dthreshold", ctypes.c_float), ("athreshold", ctypes.c_float), ("w1", ctypes.c_float), ("w2", ctypes.c_float)]
+
+
 class SrError(RuntimeError):
     pass
 
@@ -59,6 +71,8 @@ SIGNATURES = {
     "sr_mlp_gemm_tn_workspace_floats": [ctypes.c_int32, ctypes.c_int32, _i64, _vp],
     "sr_mlp_gemm_tn": [_vp, _vp],
     "sr_colsum_rows": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
+    "sr_lbs_fwd": [_vp, _vp],
+    "sr_newton_update": [_vp, _vp],
     "sr_pe_embed": [_vp, _i64, ctypes.c_int32, _vp, _vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _i64, _vp],
 }
 _RESTYPE = {"sr_mlp_gemm_tn_workspace_floats": _i64}

@@ -75,3 +75,167 @@ class MLPTranslator(nn.Module):
 
 def getTranslatorNet(device, conf):
     return MLPTranslator(conf.get_int('condlen'), multires=conf.get_int('multires')).to(device)
+
+
+# ------------------------------------------------------------------------------------------------
+# SMPL linear-blend skinning on a sampled weight volume (model/Deformer.py:86-233)
+import ctypes  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+from .. import _lib  # noqa: E402
+from ..MCAcc.grid_sampler_mine import GridSamplerMine3dFunction  # noqa: E402
+
+
+def batch_rodrigues(theta):
+    """axis-angle [M,3] -> R [M,3,3] through the half-angle quaternion, with the reference's
+    `+1e-8` inside the norm only (smpl_pytorch/util.py:35-78)."""
+    angle = torch.norm(theta + 1e-8, p=2, dim=1, keepdim=True)
+    axis = theta / angle
+    half = angle * 0.5
+    q = torch.cat([torch.cos(half), torch.sin(half) * axis], dim=1)
+    q = q / q.norm(p=2, dim=1, keepdim=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    w2, x2, y2, z2 = w * w, x * x, y * y, z * z
+    wx, wy, wz, xy, xz, yz = w * x, w * y, w * z, x * y, x * z, y * z
+    return torch.stack([w2 + x2 - y2 - z2, 2 * xy - 2 * wz, 2 * wy + 2 * xz,
+                        2 * wz + 2 * xy, w2 - x2 + y2 - z2, 2 * yz - 2 * wx,
+                        2 * xz - 2 * wy, 2 * wx + 2 * yz, w2 - x2 - y2 + z2], dim=1).view(-1, 3, 3)
+
+
+def _tree_levels(parents):
+    depth = [0] * len(parents)
+    for i in range(1, len(parents)):
+        depth[i] = depth[int(parents[i])] + 1
+    return [[i for i in range(len(parents)) if depth[i] == d] for d in range(1, max(depth) + 1)]
+
+
+class LBSkinner(nn.Module):
+    """Same constructor / buffers / call signature as the reference class.  `ws` keeps the reference's
+    logical shape [1,24,D,H,W] but lives in channels_last_3d memory so that the kernels read a corner's
+    24 weights as one 96-byte run."""
+
+    def __init__(self, ws, bmins, bmaxs, Js, parents, init_pose=None, align_corners=False):
+        super().__init__()
+
+        def as_row(v):
+            if isinstance(v, list):
+                return torch.tensor(v, dtype=torch.float).view(1, 3)
+            if isinstance(v, np.ndarray):
+                return torch.from_numpy(v.astype(np.float32)).view(1, 3)
+            return v.view(1, 3)
+        self.register_buffer('b_min', as_row(bmins))
+        self.register_buffer('b_max', as_row(bmaxs))
+        ws = torch.from_numpy(ws.astype(np.float32)) if isinstance(ws, np.ndarray) else ws.to(torch.float)
+        assert ws.dim() == 5 and ws.shape[0] == 1 and ws.shape[1] == 24
+        self.register_buffer('ws', ws.contiguous(memory_format=torch.channels_last_3d))
+        assert align_corners is False
+        self.align_corners = align_corners
+        self.register_buffer('Js', Js.view(24, 3).float())
+        self.parents = [int(p) for p in parents]
+        self._levels = _tree_levels(self.parents)
+        if init_pose is None:
+            raise NotImplementedError("the reference always builds the skinner with an init pose (network.py:843,851)")
+        if isinstance(init_pose, np.ndarray):
+            init_pose = torch.from_numpy(init_pose.astype(np.float32))
+        if init_pose.numel() == 24 * 3:
+            self.init_pose_inverse(batch_rodrigues(init_pose.view(-1, 3)).view(24, 3, 3), self.Js)
+        else:
+            self.register_buffer('init_pose', init_pose.view(24, 4, 4))
+
+    def _apply(self, fn, *a, **k):        # keep the channel-last layout across .to(device)
+        out = super()._apply(fn, *a, **k)
+        if not self.ws.is_contiguous(memory_format=torch.channels_last_3d):
+            self.ws = self.ws.contiguous(memory_format=torch.channels_last_3d)
+        return out
+
+    def init_pose_inverse(self, init_pose, Js):
+        """Inverse of the rest-pose chain per joint (Deformer.py:125-141)."""
+        R, T = [init_pose[0]], [Js[0]]
+        for i in range(1, 24):
+            pa = self.parents[i]
+            R.append(R[pa] @ init_pose[i])
+            T.append(R[pa] @ (Js[i] - Js[pa]) + T[pa])
+        inv = torch.zeros(24, 4, 4)
+        for i in range(24):
+            inv[i, :3, :3] = R[i].t()
+            inv[i, :3, 3] = -(R[i].t() @ T[i])
+            inv[i, 3, 3] = 1.
+        self.register_buffer('init_pose', inv)
+
+    def _chain(self, poses):
+        """Posed chain G_i = G_parent [R_i | J_i - J_parent] for a batch of frames -> [B,24,4,4];
+        evaluated level by level of the kinematic tree (9 batched products instead of 23)."""
+        B = poses.shape[0]
+        R = batch_rodrigues(poses.reshape(-1, 3)).view(B, 24, 3, 3)
+        rel = self.Js.clone()
+        rel[1:] = self.Js[1:] - self.Js[self.parents[1:]]
+        local = torch.cat([torch.cat([R, rel.view(1, 24, 3, 1).expand(B, 24, 3, 1)], 3),
+                           torch.tensor([0., 0., 0., 1.], device=poses.device).view(1, 1, 1, 4).expand(B, 24, 1, 4)], 2)
+        G = [None] * 24
+        G[0] = local[:, 0]
+        for level in self._levels:
+            pa = torch.stack([G[self.parents[i]] for i in level], 1)
+            prod = pa @ local[:, level]
+            for n, i in enumerate(level):
+                G[i] = prod[:, n]
+        return torch.stack(G, 1)
+
+    def posed_transforms(self, poses):
+        return self._chain(poses) @ self.init_pose.view(1, 24, 4, 4)
+
+    def posedSkeleton(self, conds):
+        poses, trans = conds
+        assert poses.shape[0] == trans.shape[0]
+        return self._chain(poses)[:, :, :3, 3]
+
+    def fused(self, ps, A, trans, batch_inds=None, with_jac=False, tps=None):
+        """No-autograd fused kernel: y (and dy/dp) for flat points [P,3] (batch_inds) or [N,V,3]."""
+        flat = ps.reshape(-1, 3).contiguous()
+        P = flat.shape[0]
+        a = _lib.SrLbsArgs()
+        A12 = A[:, :, :3, :].contiguous()
+        tr = trans.contiguous()
+        y = torch.empty_like(flat)
+        jac = torch.empty((P, 3, 3), device=flat.device) if with_jac else None
+        tp = None if tps is None else tps.reshape(-1, 3).contiguous()
+        vol = self.ws.permute(0, 2, 3, 4, 1)
+        assert vol.is_contiguous()
+        a.p, a.tp, a.P = _lib.ptr(flat), _lib.ptr(tp), P
+        a.A, a.trans, a.nframes = _lib.ptr(A12), _lib.ptr(tr), A.shape[0]
+        a.batch_inds = _lib.ptr(batch_inds)
+        a.points_per_frame = 0 if batch_inds is not None else (ps.shape[1] if ps.dim() == 3 else P)
+        a.vol, a.D, a.H, a.W = _lib.ptr(vol), vol.shape[1], vol.shape[2], vol.shape[3]
+        if not hasattr(self, "_box"):
+            self._box = (self.b_min.view(-1).tolist(), self.b_max.view(-1).tolist())
+        for i in range(3):
+            a.bmin[i], a.bmax[i] = self._box[0][i], self._box[1][i]
+        a.y, a.jac = _lib.ptr(y), _lib.ptr(jac)
+        with torch.cuda.device(flat.device):
+            _lib.call("sr_lbs_fwd", ctypes.byref(a), _lib.stream_of(flat))
+        return y.view(ps.shape), jac
+
+    def forward(self, ps, conds, batch_inds=None, **kwargs):
+        if type(ps) == list:
+            tps, ps = ps
+        else:
+            tps = ps
+        poses, trans = conds
+        batch_size = poses.shape[0]
+        assert batch_size == trans.shape[0]
+        A = self.posed_transforms(poses)
+        needs_graph = torch.is_grad_enabled() and (ps.requires_grad or tps.requires_grad or poses.requires_grad or trans.requires_grad)
+        if not needs_graph:
+            y, _ = self.fused(ps, A, trans, batch_inds, False, None if tps is ps else tps)
+            return y
+        # differentiable composition (any order): sampler (HIP fwd/bwd/dbwd) -> blend
+        nps = 2. * (tps.reshape(-1, 3) - self.b_min) / (self.b_max - self.b_min) - 1.
+        w = GridSamplerMine3dFunction.apply(self.ws, nps.reshape(1, 1, 1, -1, 3)).view(24, -1).transpose(0, 1)   # [P,24]
+        A12 = A[:, :, :3, :].reshape(batch_size, 24, 12)
+        if batch_inds is None:
+            nb, pnum, _ = ps.shape
+            assert nb == batch_size
+            T = torch.matmul(w.view(nb, pnum, 24), A12).view(nb, pnum, 3, 4)
+            return (T[..., :3] @ ps.unsqueeze(-1)).squeeze(-1) + T[..., 3] + trans.view(-1, 1, 3)
+        p = ps.reshape(-1, 3)
+        Tall = (w @ A12.permute(1, 0, 2).reshape(24, batch_size * 12)).view(-1, batch_size, 12)
+        T = torch.gather(Tall, 1, batch_inds.view(-1, 1, 1).expand(-1, 1, 12)).view(-1, 3, 4)
+        return (T[..., :3] @ p.unsqueeze(-1)).squeeze(-1) + T[..., 3] + trans[batch_inds]

@@ -1,0 +1,123 @@
+"""Ray/surface intersection helpers -- drop-ins for utils/FindSurfacePs.py of the reference.
+
+FindSurfacePs   (:5-29)   rasteriser fragments -> canonical seed points.
+OptimizeSurfacePs (:114-163) the masked Newton refiner ("the tracer").  When given this package's
+ImplicitNetwork + CompositeDeformer([MLPTranslator, LBSkinner]) it runs the fused path: per
+iteration ONE group-4 (value + 3 forward tangents) evaluation of the sdf-only SDF MLP and of the
+deformation MLP, the fused LBS+Jacobian kernel and one Newton-update kernel -- no autograd graph,
+no per-frame Python loop.  The convergence test of iteration k and the gradient of iteration k+1
+are taken from the same evaluation (the reference evaluates the same points twice).
+"""
+import ctypes
+import numpy as np
+import torch
+
+from .. import _lib
+from .. import mlp_engine as me
+from .utils import resolve_band_weights
+
+
+def FindSurfacePs(TmpVs, TmpFaces, frags):
+    N, H, W, K = frags.pix_to_face.shape
+    pix_to_face, bary_coords = frags.pix_to_face, frags.bary_coords
+    inner = (bary_coords > 0.0).all(-1) & (pix_to_face >= 0)
+    # first valid fragment per pixel (the reference: torch_scatter.scatter(cols, rows, 'min'))
+    ks = torch.arange(K, device=inner.device).view(1, 1, 1, K).expand(N, H, W, K)
+    index = torch.where(inner, ks, torch.full_like(ks, K)).amin(dim=-1)
+    hit = index < K
+    batch_inds, row_inds, col_inds = hit.nonzero(as_tuple=True)
+    sel = index[hit].view(-1, 1)
+    finds = torch.gather(pix_to_face[hit], 1, sel).view(-1) % TmpFaces.shape[0]
+    ws = torch.gather(bary_coords[hit], 1, sel.view(-1, 1, 1).expand(-1, 1, 3)).view(-1, 3)
+    initTmpPs = (TmpVs[TmpFaces[finds].view(-1)].view(-1, 3, 3) * ws[:, :, None]).sum(1)
+    return batch_inds, row_inds, col_inds, initTmpPs, finds
+
+
+class _FusedEval:
+    """Holds the per-call constants of the fused refiner (weights are packed once per call)."""
+
+    def __init__(self, sdf, deformer, defconds, ratio):
+        from ..model.network import ImplicitNetwork
+        from ..model.Deformer import MLPTranslator, LBSkinner, CompositeDeformer
+        ok = (isinstance(sdf, ImplicitNetwork) and isinstance(deformer, CompositeDeformer) and deformer.N == 2 and
+              isinstance(deformer.defs[0], MLPTranslator) and isinstance(deformer.defs[1], LBSkinner))
+        if not ok:
+            raise TypeError("fused refiner needs ImplicitNetwork + CompositeDeformer([MLPTranslator, LBSkinner])")
+        self.sdf, self.tr, self.skin = sdf, deformer.defs[0], deformer.defs[1]
+        dev = sdf.lin0.bias.device
+        with torch.no_grad():
+            r_sdf = ratio if isinstance(ratio, (float, int)) or ratio is None else ratio['sdfRatio']
+            from ..model.Embedder import band_weight_tensor
+            self.w_sdf, _ = band_weight_tensor(resolve_band_weights(sdf.multires, r_sdf), sdf.multires, dev)
+            self.w_def, _ = band_weight_tensor(resolve_band_weights(self.tr.multires, ratio['deformerRatio']), self.tr.multires, dev)
+            Ws, bs = sdf.packed_weights()
+            self.sdf_spec = me.MLPSpec(sdf.spec.layers[:-1] + [me.LayerSpec(sdf.spec.layers[-1].K, sdf.d_out, me.ACT_NONE)], sdf.spec.K0)
+            self.sdf_W = [w.contiguous() for w in Ws[:-1]] + [Ws[-1][:sdf.d_out].contiguous()]     # sdf-only last layer
+            self.sdf_b = list(bs[:-1]) + [bs[-1][:sdf.d_out].contiguous()]
+            Wd, bd = self.tr.packed_weights()
+            self.def_W, self.def_b = [w.contiguous() for w in Wd], list(bd)
+            self.conds = defconds[0].detach().contiguous().float()
+            poses, trans = defconds[1]
+            self.A = self.skin.posed_transforms(poses.detach())
+            self.trans = trans.detach().contiguous()
+
+    def _embed(self, x, L, wt, extra, index, group):
+        P = x.shape[0]
+        E = 0 if extra is None else extra.shape[1]
+        ldo = me.pad4(3 + 6 * L + E)
+        out = torch.empty((P * group, ldo), dtype=torch.float32, device=x.device)
+        _lib.call("sr_pe_embed", _lib.ptr(x), P, L, _lib.ptr(wt), _lib.ptr(extra), 0 if extra is None else extra.stride(0), E,
+                  _lib.ptr(index), group, _lib.ptr(out), ldo, _lib.stream_of(x))
+        return out
+
+    def evaluate(self, x, bi, group):
+        """-> (sdf rows [M*group, ld], offset rows [M*group, ld], y [M,3], J_lbs [M,3,3] or None)"""
+        with torch.cuda.device(x.device):
+            A0 = self._embed(x, self.sdf.multires, self.w_sdf, None, None, group)
+            sdf_rows = me.forward(self.sdf_spec, A0, self.sdf_W, self.sdf_b, group)[-1]
+            A0d = self._embed(x, self.tr.multires, self.w_def, self.conds, bi, group)
+            off_rows = me.forward(self.tr.spec, A0d, self.def_W, self.def_b, group)[-1]
+            q = x + off_rows.view(x.shape[0], group, -1)[:, 0, :3]
+            y, jl = self.skin.fused(q, self.A, self.trans, bi, with_jac=(group == 4))
+        return sdf_rows, off_rows, y, jl
+
+
+def _newton(ev, x, bi, rays, cam, group, dthr, athr, w1, w2, update):
+    sdf_rows, off_rows, y, jl = ev.evaluate(x, bi, group)
+    M = x.shape[0]
+    conv = torch.empty((M,), dtype=torch.bool, device=x.device)
+    xnew = torch.empty_like(x) if update else None
+    a = _lib.SrNewtonArgs()
+    a.M, a.group = M, group
+    a.sdf4, a.ld_sdf, a.off4, a.ld_off = _lib.ptr(sdf_rows), sdf_rows.stride(0), _lib.ptr(off_rows), off_rows.stride(0)
+    a.y, a.jlbs, a.rays, a.cam = _lib.ptr(y), _lib.ptr(jl), _lib.ptr(rays), _lib.ptr(cam)
+    a.p, a.p_out, a.converged = _lib.ptr(x), _lib.ptr(xnew), _lib.ptr(conv)
+    a.dthreshold, a.athreshold, a.w1, a.w2 = dthr, athr, w1, w2
+    with torch.cuda.device(x.device):
+        _lib.call("sr_newton_update", ctypes.byref(a), _lib.stream_of(x))
+    return xnew, conv
+
+
+def OptimizeSurfacePs(cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio, deformer, defconds, dthreshold=5.e-5,
+                      athreshold=0.02, w1=3.05, w2=1., times=5):
+    """Same contract as the reference: returns (ps, converged) and writes the refined points back
+    into `initTmpPs` (FindSurfacePs.py:152)."""
+    with torch.no_grad():
+        ev = _FusedEval(tmpSdf, deformer, defconds, ratio)
+        cam = cam_pos.detach().float().contiguous().view(3)
+        rays = rays.detach().float().contiguous()
+        P = initTmpPs.shape[0]
+        live = torch.arange(P, device=initTmpPs.device)          # indices of unfinished rays
+        finished = torch.zeros(P, dtype=torch.bool, device=initTmpPs.device)
+        for it in range(times + 1):
+            if live.numel() == 0:
+                break
+            x = initTmpPs[live].contiguous().float()
+            last = it == times
+            xnew, conv = _newton(ev, x, batch_inds[live].contiguous(), rays[live].contiguous(), cam, 1 if last else 4,
+                                 dthreshold, athreshold, w1, w2, not last)
+            finished[live[conv]] = True
+            if not last:
+                initTmpPs[live] = xnew
+                live = live[~conv]                                # compaction (device nonzero -> one sync per iteration)
+    return initTmpPs.detach(), finished
