@@ -174,6 +174,36 @@ typedef struct {
 } sr_newton_args;
 int sr_newton_update(const sr_newton_args* host_args, void* stream);
 
+/* ---------------------------------------------------------------- MCGpu (a17)
+ * Replaces MCGpu/MCGpu.cpp:20-56 mc_gpu -> MCGpu::init/MC/scaleVertices (CudaKernels.cu:524-639) and
+ * kernels K6-K9.  Two calls because the output sizes are data dependent (the reference also copies
+ * its two counters to the host between K6 and K7, CudaKernels.cu:628):
+ *   sr_mc_count : classify + exclusive scans into `workspace` (sr_mc_workspace_bytes);
+ *                 counts_dev[0] = #vertices, counts_dev[1] = #faces (2 x uint32, device memory)
+ *   sr_mc_emit  : verts [V,3] f32 = lattice position * step + min, faces [F,3] int64 (reversed winding;
+ *                 -1 where the owning cell lies outside the grid, as the reference).
+ * sdf: [nx,ny,nz] fp32 dense, index i*ny*nz + j*nz + k.  Output ORDER is deterministic: vertices by
+ * lattice-edge key (cell*3+dir), faces by (cell, triangle) -- the reference's atomicAdd order is not
+ * reproducible even by itself; compare after canonicalisation.  No growing singleton, no
+ * 5%-of-cells scratch guess (CudaKernels.cu:590-592): the caller sizes the outputs exactly. */
+int64_t sr_mc_workspace_bytes(int32_t nx, int32_t ny, int32_t nz);
+int sr_mc_count(const float* sdf, int32_t nx, int32_t ny, int32_t nz, float iso, void* workspace, uint32_t* counts_dev, void* stream);
+int sr_mc_emit(const float* sdf, int32_t nx, int32_t ny, int32_t nz, float iso, const void* workspace, float xstep, float ystep,
+               float zstep, float xmin, float ymin, float zmin, float* verts, int64_t* faces, void* stream);
+
+/* ---------------------------------------------------------------- small per-element ops
+ * sr_svd3x3: batched 3x3 SVD on device, A = U diag(S) V^T, S descending -- replaces
+ *   `torch.svd(Jacobs.cpu())` of the deformation regulariser (model/network.py:576).  A,U,V [n,3,3], S [n,3].
+ * sr_splat_fwd/bwd: soft point-splat silhouette, the stand-in for the pytorch3d PointsRasterizer +
+ *   AlphaCompositor call of model/network.py:497 (third-party code, parity unpinned -- SURVEY.md 8(c)):
+ *   logT[img,y,x] += log(1 - a), a = 1 - |pixel - p|^2 / r^2 for pixels within r (pixels); mask = 1 - exp(logT).
+ *   pix [nimg, pts_per_img, 2] (x=col, y=row); vis [nimg*pts_per_img] u8 nullable; logT zero-filled by the caller. */
+int sr_svd3x3(const float* A, int64_t n, float* U, float* S, float* V, void* stream);
+int sr_splat_fwd(const float* pix, const uint8_t* vis, int64_t nimg, int64_t pts_per_img, int32_t H, int32_t W, float radius_px,
+                 float* logT, void* stream);
+int sr_splat_bwd(const float* pix, const uint8_t* vis, int64_t nimg, int64_t pts_per_img, int32_t H, int32_t W, float radius_px,
+                 const float* logT, const float* gmask, float* gpix, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

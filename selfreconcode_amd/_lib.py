@@ -73,9 +73,15 @@ SIGNATURES = {
     "sr_colsum_rows": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
     "sr_lbs_fwd": [_vp, _vp],
     "sr_newton_update": [_vp, _vp],
+    "sr_mc_workspace_bytes": [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32],
+    "sr_mc_count": [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp],
+    "sr_mc_emit": [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp] + [ctypes.c_float] * 6 + [_vp, _vp, _vp],
+    "sr_svd3x3": [_vp, _i64, _vp, _vp, _vp, _vp],
+    "sr_splat_fwd": [_vp, _vp, _i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp],
+    "sr_splat_bwd": [_vp, _vp, _i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp, _vp],
     "sr_pe_embed": [_vp, _i64, ctypes.c_int32, _vp, _vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _i64, _vp],
 }
-_RESTYPE = {"sr_mlp_gemm_tn_workspace_floats": _i64}
+_RESTYPE = {"sr_mlp_gemm_tn_workspace_floats": _i64, "sr_mc_workspace_bytes": _i64}
 
 _fn = {}
 for _name, _args in SIGNATURES.items():

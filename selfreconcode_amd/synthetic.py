@@ -139,3 +139,110 @@ def sphere_sdf_params(seed=7, bias=0.6, multires=6, feat=256):
         sd[f"lin{l}.weight_v"] = w
         sd[f"lin{l}.bias"] = b
     return sd
+
+
+# ------------------------------------------------------------------------------------------------
+# Synthetic sequence + scene builder: the tensor contract of
+# dataset/dataset.py (poses / trans / per-frame codes as dense learnable tensors, one camera),
+# resident on the GPU instead of being re-uploaded from the host at every call.
+class SyntheticSequence:
+    def __init__(self, frame_num=64, H=540, W=540, device="cuda:0", seed=0):
+        self.frame_num, self.H, self.W = frame_num, H, W
+        self.device = torch.device(device)
+        dev = self.device
+        # smooth pose / translation tracks (low-frequency sines so that the DCT term is meaningful)
+        t = torch.linspace(0, 1, frame_num).view(-1, 1, 1)
+        ph = det_tensor((1, 24, 3), 900 + seed, 3.14)
+        self.poses = (0.12 * torch.sin(2 * np.pi * t + ph) * det_tensor((1, 24, 3), 901 + seed, 1.0)).to(dev).requires_grad_(True)
+        self.trans = (0.04 * torch.sin(2 * np.pi * t.view(-1, 1) + det_tensor((1, 3), 902 + seed, 3.14))).to(dev).requires_grad_(True)
+        self.shape = torch.zeros(10, device=dev)
+        self.conds = [(0.1 * det_tensor((frame_num, 128), 903 + seed, 1.0)).to(dev).requires_grad_(True),
+                      (0.1 * det_tensor((frame_num, 256), 904 + seed, 1.0)).to(dev).requires_grad_(True)]
+        self.cond_ns = ['deformer', 'render']
+        f = 1.2 * max(H, W)
+        self.camera_params = {'focal_length': torch.tensor([f, f], device=dev),
+                              'princeple_points': torch.tensor([W / 2.0, H / 2.0], device=dev),
+                              'cam2world_coord_quat': torch.tensor([0., 0., 1., 0.], device=dev),   # R = diag(-1, 1, -1)
+                              'world2cam_coord_trans': torch.tensor([0., 0.15, 2.4], device=dev)}
+        self.video_segmented_index = []
+
+    def learnable_weights(self):
+        ws = [c for c in self.conds if c.requires_grad]
+        ws += [v for v in self.camera_params.values() if v.requires_grad]
+        ws += [v for v in (self.poses, self.trans) if v.requires_grad]
+        return ws
+
+    def get_grad_parameters(self, idxs, device=None):
+        return self.poses[idxs], self.trans[idxs], self.conds[0][idxs], self.conds[1][idxs]
+
+    def get_camera_parameters(self, N, device=None):
+        q = self.camera_params['cam2world_coord_quat'].view(1, 4)
+        q = q / q.norm(p=2, dim=1, keepdim=True)
+        w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = torch.stack([w * w + x * x - y * y - z * z, 2 * x * y - 2 * w * z, 2 * w * y + 2 * x * z,
+                         2 * w * z + 2 * x * y, w * w - x * x + y * y - z * z, 2 * y * z - 2 * w * x,
+                         2 * x * z - 2 * w * y, 2 * w * x + 2 * y * z, w * w - x * x - y * y + z * z], dim=1).view(1, 3, 3)
+        return (self.camera_params['focal_length'].view(1, 2).expand(N, 2), self.camera_params['princeple_points'].view(1, 2).expand(N, 2),
+                R.expand(N, 3, 3), self.camera_params['world2cam_coord_trans'].view(1, 3).expand(N, 3), self.H, self.W)
+
+    def get_batchframe_data(self, name, fids, batchsize):
+        """Window of `batchsize` frames around each id, clamped to the sequence (dataset.py:128-147)."""
+        assert batchsize < self.frame_num
+        data = getattr(self, name)
+        starts = (fids - batchsize // 2).clamp(min=0, max=self.frame_num - batchsize)
+        return data[starts.view(-1, 1) + torch.arange(0, batchsize, device=fids.device).view(1, batchsize)], fids - starts
+
+    def batch(self, frame_ids):
+        """Synthetic observations: an elliptic ground-truth silhouette around the projected body and uniform-noise
+        colour / normal images of the right shape."""
+        N, H, W, dev = len(frame_ids), self.H, self.W, self.device
+        ys, xs = torch.meshgrid(torch.arange(H, device=dev).float(), torch.arange(W, device=dev).float(), indexing='ij')
+        f = float(self.camera_params['focal_length'][0]); cx = float(self.camera_params['princeple_points'][0]); cy = float(self.camera_params['princeple_points'][1])
+        Tz = float(self.camera_params['world2cam_coord_trans'][2])
+        masks = []
+        for i in range(N):
+            tr = self.trans[int(frame_ids[i])].detach()
+            ux = cx + f * float(tr[0]) / Tz
+            uy = cy - f * (float(tr[1]) + float(self.camera_params['world2cam_coord_trans'][1])) / Tz
+            rx, ry = f * 0.56 / Tz, f * 0.63 / Tz
+            masks.append((((xs - ux) / rx) ** 2 + ((ys - uy) / ry) ** 2 < 1.0).float())
+        g = torch.Generator(device=dev); g.manual_seed(1234 + int(frame_ids[0]))
+        return {'img': torch.rand((N, H, W, 3), device=dev, generator=g) * 2 - 1, 'mask': torch.stack(masks),
+                'normal': torch.rand((N, H, W, 3), device=dev, generator=g) * 2 - 1}
+
+
+COARSE_RESOLUTIONS = [(14 + 1, 20 + 1, 8 + 1), (28 + 1, 40 + 1, 16 + 1), (56 + 1, 80 + 1, 32 + 1), (112 + 1, 160 + 1, 64 + 1),
+                      (224 + 1, 320 + 1, 128 + 1)]                                    # train.py:29-35 (W,H,D)
+
+
+def build_synthetic_scene(device="cuda:0", frame_num=64, H=540, W=540, stage="coarse", resolutions=None, lbs_volume_shape=(65, 225, 129),
+                          conf=None, seed=0):
+    """SDF (near-sphere geometric init), deformer (MLPTranslator + LBS on a synthetic weight volume), render net,
+    Seg3dLossless engine, orchestrator and dataset, wired like model/network.py::getOptNet (:828-909)."""
+    from .config import default_config
+    from .model.network import getTmpSdf
+    from .model.Deformer import MLPTranslator, LBSkinner, CompositeDeformer
+    from .model.RenderNet import RenderingNetwork_view_norm
+    from .model.optim_network import OptimNetwork
+    from .MCAcc import Seg3dLossless
+    from .utils.utils import smpl_tmp_Apose, DCTNullSpace
+    conf = conf or default_config()
+    sdf = getTmpSdf(device, conf.get_int('sdf_net.multires'), 0.6, conf.get_int('render_net.condlen'))
+    sdf.load_state_dict(sphere_sdf_params(7 + seed), strict=True)
+    torch.manual_seed(seed)
+    tr = MLPTranslator(conf.get_int('mlp_deformer.condlen'), conf.get_int('mlp_deformer.multires')).to(device)
+    vol = synthetic_lbs_volume(lbs_volume_shape, device=device)
+    skin = LBSkinner(vol, LBS_BMIN, LBS_BMAX, synthetic_joints(), np.array(SMPL_PARENTS),
+                     init_pose=torch.from_numpy(smpl_tmp_Apose(conf.get_int('train.skinner_pose_type'))), align_corners=False).to(device)
+    deformer = CompositeDeformer([tr, skin]).to(device)
+    rend = RenderingNetwork_view_norm(conf.get_int('render_net.condlen'), 'idr', 9, 3, [512, 512, 512, 512], True,
+                                      multires_n=conf.get_int('render_net.multires_n'), multires_v=conf.get_int('render_net.multires_v')).to(device)
+    engine = Seg3dLossless(query_func=None, b_min=LBS_BMIN, b_max=LBS_BMAX, resolutions=resolutions or COARSE_RESOLUTIONS,
+                           align_corners=False, balance_value=0.0).to(device)
+    net = OptimNetwork(sdf, deformer, engine, None, rend, conf=conf.get_config('loss_' + stage)).to(device)
+    net.remesh_intersect = conf.get_int(f'train.{stage}.point_render.remesh_intersect')
+    net.point_radius = conf.get_float(f'train.{stage}.point_render.radius')
+    ds = SyntheticSequence(frame_num, H, W, device, seed)
+    net.dataset = ds
+    net.dctnull = DCTNullSpace(10, 30).to(device)
+    return net, ds, conf
