@@ -1,0 +1,138 @@
+#!/usr/bin/env python
+"""bench.py -- `train.py`-equivalent iterations/s of the SelfRecon SDF-optimisation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one full training iteration of BASELINE.json configs[1] (female-3-casual-like: 540x540, coarse
+stage, 3 frames x 2048 rays per rank): template deformation + silhouette mask loss + template SGD step, ray
+seeding + fused Newton refiner, eikonal / deformation-regulariser / DCT / colour / normal losses, backward,
+implicit-gradient propagation, Adam step, and the periodic remesh (Seg3dLossless + marching cubes every 30
+iterations -- with the default K=30 exactly one falls inside the timed region).  Inputs are synthetic
+ and resident in HBM before the timed region.  The two pytorch3d rasterisation calls of the
+reference are third-party code outside its repository; they are replaced by in-repo stand-ins.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from selfreconcode_amd import dist as srdist
+    from selfreconcode_amd import mlp_engine
+    from selfreconcode_amd.synthetic import build_synthetic_scene
+    rank, world, device = srdist.init_from_env("cuda")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    FRAMES_PER_RANK, RAYS = 3, 2048
+    net, ds, conf = build_synthetic_scene(device=device, frame_num=64 if world <= 8 else 8 * world)
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.Adam([{'params': ds.learnable_weights()}, {'params': params}], lr=conf.get_float('train.learning_rate'))
+    bucket = srdist.GradBucket(list(ds.learnable_weights()) + params)
+    ratio_of = lambda it: {'sdfRatio': 1., 'deformerRatio': it / 2500. + 0.5, 'renderRatio': 1.}
+
+    def frames_of(it):
+        base = (it * FRAMES_PER_RANK * world) % (ds.frame_num - FRAMES_PER_RANK * world + 1)
+        glob = torch.arange(base, base + FRAMES_PER_RANK * world, device=device)
+        return srdist.shard_frames(glob, rank, world)
+
+    batches = {}                                           # synthetic observations, built before the timed region
+    for it in range(args.warmup + args.steps):
+        f = frames_of(it)
+        key = int(f[0])
+        if key not in batches:
+            batches[key] = ds.batch(f)
+    conv = []
+
+    def step(it):
+        f = frames_of(it)
+        opt.zero_grad(set_to_none=True)
+        loss = net(batches[int(f[0])], RAYS, ratio_of(it), f)
+        loss.backward()
+        net.propagateTmpPsGrad(f, ratio_of(it))
+        bucket.all_reduce_mean()
+        opt.step()
+        conv.append(net.info['rayInfo'])
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        step(it)
+    conv.clear()
+    mlp_engine.PROFILE.reset(enabled=True)                 # HIP-event pairs around every MLP GEMM launch (this stream)
+    barrier()
+    t0 = time.perf_counter()
+    for it in range(args.warmup, args.warmup + args.steps):
+        step(it)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t)
+    prof = mlp_engine.PROFILE.summary()
+    mlp_engine.PROFILE.reset(enabled=False)
+
+    # secondary headline: SDF MLP forward throughput (no-grad, 393216 samples per call)
+    with torch.no_grad():
+        x = (torch.rand(393216, 3, device=device) - 0.5) * 1.6
+        for _ in range(2):
+            net.sdf(x, 1.0)
+        torch.cuda.synchronize(); s = time.perf_counter()
+        for _ in range(5):
+            net.sdf(x, 1.0)
+        torch.cuda.synchronize(); sdf_gs = 5 * x.shape[0] / (time.perf_counter() - s) / 1e9
+
+    if rank != 0:
+        return
+    rays_total = sum(int(r[0]) for r in conv); rays_conv = sum(int(r[1]) for r in conv)
+    V = int(net.TmpVs.shape[0])
+    out = {
+        "metric": "train.py-equivalent iterations/sec (540x540, 2048 rays/frame x 3 frames per GPU)",
+        "value": round(args.steps * world / elapsed, 4), "unit": "iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: female-3-casual-like 540x540, coarse stage, 3 frames x 2048 rays per rank, full iteration "
+                               "(template deform + mask loss + SGD, seeds + Newton refiner, eikonal/def-regu/DCT/colour/normal, backward, "
+                               "implicit-grad propagation, Adam, remesh every 30 it)",
+                   "frames_per_gpu": FRAMES_PER_RANK, "rays_per_frame": RAYS, "image": [ds.H, ds.W], "template_vertices": V,
+                   "rays_per_iter": round(rays_total / max(len(conv), 1), 1), "rays_converged_frac": round(rays_conv / max(rays_total, 1), 4),
+                   "rasterisation": "in-repo stand-ins (vertex z-buffer seeds + soft point splat); pytorch3d is third-party, not in the reference repo",
+                   "parallelism": f"frame-parallel dp{world}: one flat grad all-reduce/step + template-vertex grad all-reduce"},
+        "sdf_mlp_gsamples_per_s": round(sdf_gs, 5),
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<2,2,2,2> (fp32 MFMA 32x32x2 layer GEMM, fused epilogue)",
+                     "achieved": prof["tflops"], "peak": 157.3, "unit": "TFLOP/s", "frac": round(prof["tflops"] / 157.3, 4),
+                     "launches": prof["launches"], "avg_launch_us": prof["avg_us"], "flop_per_launch": prof["avg_flop"],
+                     "traffic": None},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.cpu_baseline import estimate_iteration_seconds       # checker-side code, baseline leg only
+        sec, parts, threads = estimate_iteration_seconds(V, rays_total / max(len(conv), 1), FRAMES_PER_RANK,
+                                                         conv_frac=rays_conv / max(rays_total, 1))
+        out["cpu_baseline"] = {"value": round(1.0 / sec, 5), "unit": "iterations/s", "cores": threads, "kind": "port",
+                               "sample": "CPU oracle (restated reference PyTorch path) timed per loss term on 1024-point / 256-ray samples, "
+                                         "scaled linearly to this run's point counts; rasterisation + remesh excluded",
+                               "seconds_per_iteration": round(sec, 3), "parts_s": {k: round(v, 3) for k, v in parts.items()}}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""TEST/BENCH INFRASTRUCTURE -- times the CPU oracle (oracle/torch_oracle.py, a restatement of the
+reference's own PyTorch path) on a BOUNDED sample of one training iteration and scales linearly to the
+full point counts.  Used only by bench.py's `cpu_baseline` leg (kind "port"): a reported baseline, not a
+target.  The reference's full train.py cannot run on CPU (CUDA-only extensions + pytorch3d), so this is
+a component-sum estimate of one iteration: every MLP / LBS / refiner term of SURVEY.md 3.2 is timed
+through the oracle on a sample and multiplied up; rasterisation and remesh are left out (they favour
+the CPU number)."""
+import os
+import time
+import torch
+from . import torch_oracle as orc
+from . import fixtures as fx
+
+RATIO = {'sdfRatio': 1.0, 'deformerRatio': 0.6, 'renderRatio': 1.0}
+
+
+def _t(fn, reps=1):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps
+
+
+def estimate_iteration_seconds(V, P, N, conv_frac=0.5, tracer_iters=6.0, sample=1024, threads=None):
+    threads = threads or os.cpu_count()
+    torch.set_num_threads(threads)
+    sdf = {k: v.clone().requires_grad_(True) for k, v in fx.sphere_sdf_params(7).items()}
+    trp = {k: v.clone().requires_grad_(True) for k, v in fx.det_params(fx.DEF_SPEC, 202, last_scale=0.05).items()}
+    rnd = {k: v.clone().requires_grad_(True) for k, v in fx.det_params(fx.REND_SPEC, 303).items()}
+    vol = fx.synthetic_lbs_volume((17, 57, 33))
+    Js = fx.synthetic_joints()
+    import math
+    apose = torch.zeros(24, 3); apose[1, 2] = 7 / 180 * math.pi; apose[2, 2] = -7 / 180 * math.pi
+    apose[16, 2] = -55 / 180 * math.pi; apose[17, 2] = 55 / 180 * math.pi
+    ip = orc.make_init_pose_inverse(apose, Js)
+    poses = fx.det_tensor((N, 24, 3), 21, 0.1).requires_grad_(True); trans = fx.det_tensor((N, 3), 22, 0.05).requires_grad_(True)
+    conds = fx.det_tensor((N, 128), 13, 0.1).requires_grad_(True)
+    kw = dict(ws=vol, b_min=torch.tensor(fx.LBS_BMIN), b_max=torch.tensor(fx.LBS_BMAX), Js=Js, init_pose=ip)
+    n = sample
+    pts = (fx.det_tensor((n, 3), 1, 0.5) * torch.tensor([0.6, 1.0, 0.3])).requires_grad_(True)
+    bi = torch.arange(n) % N
+
+    def deform(p, b):
+        q, _ = orc.translator_forward(trp, p, conds, b, RATIO)
+        return orc.lbs_forward(q, poses, trans, batch_inds=b, **kw)
+
+    parts = {}
+    # step 3+6: deformer on the template fwd+bwd, LBS-only consistency term, |f(TmpVs)|
+    def a():
+        d = deform(pts, bi)
+        l = orc.lbs_forward(pts, poses, trans, batch_inds=bi, **kw)
+        ((d - l) ** 2).sum().backward()
+    parts['template_deformer'] = _t(a) * (N * V / n)
+    def c():
+        orc.sdf_forward(sdf, pts, 1.0)[0].abs().mean().backward()
+    parts['template_sdf'] = _t(c) * (V / n)
+    # step 8: refiner
+    nr = min(256, n)
+    p0 = pts[:nr].detach().clone(); rays = torch.nn.functional.normalize(fx.det_tensor((nr, 3), 3, 1.0), dim=1)
+    def tr():
+        with torch.enable_grad():
+            orc.optimize_surface_ps(torch.tensor([0., 0., 2.4]), rays, p0.clone(), bi[:nr], lambda p: orc.sdf_forward(sdf, p, RATIO)[0],
+                                    lambda p, b: deform(p, b), 5e-5, 0.04, 3.05, 1., 2)
+    parts['refiner'] = _t(tr) / 2.0 * tracer_iters * (P / nr)
+    # step 9: eikonal
+    def e():
+        x = pts.detach().clone().requires_grad_(True)
+        y, _ = orc.sdf_forward(sdf, x, 1.0)
+        g = torch.autograd.grad(y, x, torch.ones_like(y), create_graph=True)[0]
+        ((g.norm(2, dim=-1) - 1) ** 2).mean().backward()
+    parts['eikonal'] = _t(e) * ((P + 4096) * 7 / 6 / n)
+    # step 11: deformation regulariser
+    def r():
+        x = pts.detach().clone().requires_grad_(True)
+        d, _ = orc.translator_forward(trp, x, conds, bi, RATIO)
+        J = orc.compute_jacobian(x, d, True, True)
+        s = torch.log(torch.linalg.svdvals(J))
+        orc.gm_robust((s * s).sum(1), 0.5, True).mean().backward()
+    parts['def_regu'] = _t(r) * (2 * (P + 4096) * N / n)
+    # steps 13+14 (+ propagate): colour and normal branches on the converged rays
+    nc = min(256, n)
+    def cn():
+        x = pts[:nc].detach().clone().requires_grad_(True)
+        y, feat = orc.sdf_forward(sdf, x, 1.0)
+        nx = torch.autograd.grad(y, x, torch.ones_like(y), create_graph=True)[0]
+        nx = nx / nx.norm(dim=1, keepdim=True)
+        d = deform(x, bi[:nc])
+        J = orc.compute_jacobian(x, d, True, True)
+        Ji, _ = orc.DiffMinv.apply(J)
+        cr = (Ji @ rays[:nc].view(-1, 3, 1)).view(-1, 3)
+        cr = cr / cr.norm(dim=1, keepdim=True)
+        col = orc.render_forward(rnd, x, nx, cr, feat, RATIO)
+        d2 = deform(x, bi[:nc])
+        J2 = orc.compute_jacobian(x, d2, True, True)
+        gn = (J2.transpose(-2, -1) @ rays[:nc].view(-1, 3, 1)).view(-1, 3)
+        (col.abs().sum() + (gn - nx).norm(dim=1).sum()).backward()
+        # implicit-gradient propagation: 3 SDF + 2 deformer evaluations with parameter gradients
+        orc.sdf_forward(sdf, x.detach(), 1.0)[0].sum().backward()
+        deform(x.detach(), bi[:nc]).sum().backward()
+    parts['color_normal_propagate'] = _t(cn) * (P * conv_frac / nc)
+    total = sum(parts.values())
+    return total, parts, threads

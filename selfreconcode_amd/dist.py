@@ -1,0 +1,79 @@
+"""Frame-parallel data parallelism: one process per GPU, every rank optimises its own
+frames of the global batch; ONE flat all-reduce of all gradients per optimizer step (RCCL over xGMI
+when the backend is "nccl"; "gloo" for the CPU tests).  The reference has no distributed code at all
+(single process, single GPU); the semantics preserved here are listed in DESIGN.md "multi-GPU".
+"""
+import os
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(device_type="cuda"):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if device_type == "cuda":
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    else:
+        device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl" if device_type == "cuda" else "gloo", rank=rank, world_size=world)
+    return rank, world, device
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class GradBucket:
+    """All gradients of `tensors` as ONE contiguous fp32 buffer -> one collective per step.
+    15.2 MB of MLP parameters + the dense per-frame learnables (poses, trans, codes: every row moves
+    through Adam's moments each step, so they are reduced densely)."""
+
+    def __init__(self, tensors):
+        self.tensors = [t for t in tensors if t.requires_grad]
+        self.numel = sum(t.numel() for t in self.tensors)
+        self.flat = None
+
+    def all_reduce_mean(self):
+        if not is_distributed() or not self.tensors:
+            return
+        dev = self.tensors[0].device
+        if self.flat is None or self.flat.device != dev:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        off = 0
+        for t in self.tensors:
+            n = t.numel()
+            if t.grad is None:
+                self.flat[off:off + n].zero_()
+            else:
+                self.flat[off:off + n].copy_(t.grad.reshape(-1))
+            off += n
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.div_(dist.get_world_size())
+        off = 0
+        for t in self.tensors:
+            n = t.numel()
+            g = self.flat[off:off + n].view_as(t)
+            if t.grad is None:
+                t.grad = g.clone()
+            else:
+                t.grad.copy_(g)
+            off += n
+
+
+def all_reduce_mean_(tensor):
+    """In-place mean over ranks (used for the template-vertex gradient before its SGD step, caveat A)."""
+    if is_distributed() and tensor is not None:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+        tensor.div_(dist.get_world_size())
+    return tensor
+
+
+def shard_frames(global_frame_ids, rank, world):
+    """rank r takes frames batch[r::R] of the global batch."""
+    return global_frame_ids[rank::world]

@@ -70,6 +70,32 @@ class MLPSpec:
         return MLPSpec(layers, K0)
 
 
+class _GemmProfile:
+    """Optional HIP-event timing of every layer-GEMM launch on the launching stream (bench.py's roofline
+    leg): achieved = sum(2 M N K) / sum(event time).  Off by default: zero overhead in the product path."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def reset(self, enabled):
+        self.enabled = enabled
+        self.records = []
+
+    def summary(self):
+        if not self.records:
+            return {"tflops": 0.0, "launches": 0, "avg_us": 0.0, "avg_flop": 0.0}
+        torch.cuda.synchronize()
+        flop = sum(r[2] for r in self.records)
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        n = len(self.records)
+        return {"tflops": round(flop / (ms * 1e-3) / 1e12, 3), "launches": n, "avg_us": round(ms * 1e3 / n, 3),
+                "avg_flop": round(flop / n, 1)}
+
+
+PROFILE = _GemmProfile()
+
+
 def _gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, group, act, mode, out_scale=1.0, aux=None, ldaux=0, naux_fwd=0,
              nact_bwd=0, aux_scale=1.0):
     a = _lib.SrGemmArgs()
@@ -78,6 +104,13 @@ def _gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, group, act, mode, out_scale=
     a.bias = _lib.ptr(bias)
     a.group, a.act, a.mode, a.out_scale = group, act, mode, out_scale
     a.aux, a.ldaux, a.naux_fwd, a.nact_bwd, a.aux_scale = _lib.ptr(aux), ldaux, naux_fwd, nact_bwd, aux_scale
+    if PROFILE.enabled and M >= 128 and N > 32:      # the 128x128-tile kernel only
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.call("sr_mlp_gemm_nt", ctypes.byref(a), _lib.stream_of(C))
+        e1.record()
+        PROFILE.records.append((e0, e1, 2.0 * M * N * K))
+        return
     _lib.call("sr_mlp_gemm_nt", ctypes.byref(a), _lib.stream_of(C))
 
 

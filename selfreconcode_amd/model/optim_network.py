@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import dist as srdist
 from ..ext import MCGpu
 from ..ext.FastMinv import Fast3x3Minv
 from ..ops import singular_values_3x3, splat_silhouette
@@ -281,6 +282,7 @@ class OptimNetwork(nn.Module):
             loss = loss + consistent_loss * cw
         self.TmpOptimizer.zero_grad()
         loss.backward()
+        srdist.all_reduce_mean_(self.TmpVs.grad)     # shared template: exact batch semantics across ranks
         self.TmpOptimizer.step()
         mnfld_pred = self.sdf(self.TmpVs, ratio).view(-1)
         sdf_loss = (mnfld_pred + self.sdfShrinkRadius).abs().mean()
