@@ -23,7 +23,7 @@ def _t(fn, reps=1):
 
 
 def estimate_iteration_seconds(V, P, N, conv_frac=0.5, tracer_iters=6.0, sample=1024, threads=None):
-    threads = threads or os.cpu_count()
+    threads = threads or min(os.cpu_count(), 16)     # small-op oracle: more threads only add sync overhead
     torch.set_num_threads(threads)
     sdf = {k: v.clone().requires_grad_(True) for k, v in fx.sphere_sdf_params(7).items()}
     trp = {k: v.clone().requires_grad_(True) for k, v in fx.det_params(fx.DEF_SPEC, 202, last_scale=0.05).items()}
