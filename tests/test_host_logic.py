@@ -1,0 +1,49 @@
+"""CPU-only tests of the host logic: config parser, Seg3dLossless bookkeeping (pure torch, device agnostic),
+synthetic-input determinism, tangent-interleaving helpers."""
+import os
+import numpy as np
+import torch
+from oracle import fixtures as fx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_default_config_matches_the_documented_values():
+    from selfreconcode_amd.config import default_config, parse_hocon
+    d = default_config()
+    assert d.get_int('train.sample_pix_num') == 2048 and d.get_float('loss_coarse.def_regu.c') == 0.5
+    assert d.get_int('loss_fine.sample_pix_num') == 6144 and 'pc_weight.mask_weight' not in d.get_config('loss_coarse')
+    c = parse_hocon('a { b = 3\n c = "x"\n l = [\n 1\n 2\n ]\n d { e = -0.5 } }\n f = true')
+    assert c.get_int('a.b') == 3 and c.get_string('a.c') == 'x' and c.get_list('a.l') == [1, 2] and c.get_float('a.d.e') == -0.5 and c.get_bool('f')
+
+
+def test_seg3d_bookkeeping_reproduces_the_reference_run(golden):
+    from selfreconcode_amd.MCAcc.seg3d_lossless import Seg3dLossless
+    g = golden("seg3d")
+
+    def ell(points):
+        c = torch.tensor([0.05, -0.1, 0.02]).view(1, 1, 3); a = torch.tensor([0.45, 0.8, 0.25]).view(1, 1, 3)
+        return (((points - c) / a).norm(dim=-1) - 1.0).view(1, 1, -1) * 0.25
+    eng = Seg3dLossless(ell, [-0.8, -1.25, -0.4], [0.8, 0.95, 0.4], [(5, 7, 3), (9, 13, 5), (17, 25, 9), (33, 49, 17)], balance_value=0.0)
+    vol = eng.forward()
+    assert eng.stats["queries"] == int(g["nq"]) and torch.equal(vol[0, 0], g["vol"])
+
+
+def test_synthetic_inputs_are_pure_functions():
+    a, b = fx.det_tensor((5, 7), 3, 2.0), fx.det_tensor((5, 7), 3, 2.0)
+    assert torch.equal(a, b) and float(a.abs().max()) <= 2.0 and not torch.equal(a, fx.det_tensor((5, 7), 4, 2.0))
+    sd = fx.sphere_sdf_params(7)
+    assert sd["lin3.weight_v"].shape == (473, 512) and sd["lin8.weight_v"].shape == (257, 512) and float(sd["lin8.bias"][0]) == -0.6
+    vol = fx.synthetic_lbs_volume((5, 6, 7))
+    assert vol.shape == (1, 24, 5, 6, 7) and torch.allclose(vol.sum(1), torch.ones(1, 5, 6, 7), atol=1e-5)
+
+
+def test_mlp_spec_shapes_match_the_reference_layers():
+    from selfreconcode_amd.mlp_engine import MLPSpec, pad4
+    s = MLPSpec.sdf()
+    assert [(l.K, l.N, l.nfill) for l in s.layers] == [(39, 512, 0), (512, 512, 0), (512, 512, 0), (512, 473, 39), (512, 512, 0),
+                                                       (512, 512, 0), (512, 512, 0), (512, 512, 0), (512, 257, 0)]
+    d = MLPSpec.relu_mlp(167, [512, 512, 512, 512, 3])
+    assert [(l.K, l.N) for l in d.layers] == [(167, 512), (512, 512), (512, 512), (512, 512), (512, 3)] and pad4(167) == 168
+    flops = sum(2 * l.K * l.N for l in s.layers)
+    assert flops == 3933184
