@@ -123,6 +123,9 @@ typedef struct {
   float* dW; int64_t lddw;
   float* partial;
   int32_t R, N, K, splits, accumulate;
+  /* optional fused bias gradient: db[n] = sum over primal rows (r % group == 0) of Z[r][n];
+   * db_partial: workspace of splits*N floats.  Both NULL to skip. */
+  float* db; float* db_partial; int32_t group;
 } sr_gemm_tn_args;
 int64_t sr_mlp_gemm_tn_workspace_floats(int32_t R, int32_t N, int64_t lddw, int32_t* host_splits_out);
 int sr_mlp_gemm_tn(const sr_gemm_tn_args* host_args, void* stream);
@@ -154,6 +157,10 @@ typedef struct {
   float* jac;      /* [P,3,3] dy/dp, nullable */
 } sr_lbs_args;
 int sr_lbs_fwd(const sr_lbs_args* host_args, void* stream);
+/* Reverse sweep of sr_lbs_fwd for a cotangent ybar [P,3] (replaces the autograd backward of the K3/K4 sampler +
+ * per-frame blend, model/Deformer.py:207-233): pbar = (dy/dp)^T ybar, Abar [nframes,24,12] += w_j ybar (x) [p;1],
+ * transbar [nframes,3] += ybar.  Abar / transbar are accumulated (zero-fill first); each output is nullable. */
+int sr_lbs_bwd(const sr_lbs_args* host_args, const float* ybar, float* pbar, float* Abar, float* transbar, void* stream);
 
 /* ---------------------------------------------------------------- ray/surface refiner step (a12)
  * One iteration body of utils/FindSurfacePs.py::OptimizeSurfacePs (:115-126 check, :135-151 step)

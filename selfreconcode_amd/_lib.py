@@ -28,7 +28,7 @@ class SrGemmArgs(ctypes.Structure):
 class SrGemmTnArgs(ctypes.Structure):
     _fields_ = [("Z", _vp), ("ldz", _i64), ("A", _vp), ("lda", _i64), ("dW", _vp), ("lddw", _i64), ("partial", _vp),
                 ("R", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("splits", ctypes.c_int32),
-                ("accumulate", ctypes.c_int32)]
+                ("accumulate", ctypes.c_int32), ("db", _vp), ("db_partial", _vp), ("group", ctypes.c_int32)]
 
 
 class SrLbsArgs(ctypes.Structure):
@@ -72,6 +72,7 @@ SIGNATURES = {
     "sr_mlp_gemm_tn": [_vp, _vp],
     "sr_colsum_rows": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
     "sr_lbs_fwd": [_vp, _vp],
+    "sr_lbs_bwd": [_vp, _vp, _vp, _vp, _vp, _vp],
     "sr_newton_update": [_vp, _vp],
     "sr_mc_workspace_bytes": [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32],
     "sr_mc_count": [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp],

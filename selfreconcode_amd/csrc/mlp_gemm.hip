@@ -295,6 +295,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(sr_gemm_tn_args g, int row
     }
   };
 
+  // bias gradient rides along: workgroups of the first K-tile also sum their Z tile over the primal rows
+  const bool do_bias = g.db_partial != nullptr && k0 == 0;
+  const int bcol = threadIdx.x & 127, bhalf = threadIdx.x >> 7;
+  float bsum = 0.f;
   const int nsteps = (r_end - r_begin + TBR - 1) / TBR;
   if (nsteps > 0) {
     load(r_begin);
@@ -315,8 +319,22 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(sr_gemm_tn_args g, int row
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1, x0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1, x1, acc[1][1], 0, 0, 0);
     }
+    if (do_bias) {
+      const int rbase = r_begin + t * TBR;
+#pragma unroll
+      for (int row = 0; row < TBR / 2; ++row) {
+        const int r = 2 * row + bhalf;
+        if ((rbase + r) % g.group == 0) bsum += Zs[cur][r * TLD + bcol];   // rows beyond r_end were zero-filled
+      }
+    }
     if (t + 1 < nsteps) store(cur ^ 1);
     __syncthreads();
+  }
+  if (do_bias) {
+    float* red = &Xs[0][0];
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x < 128 && n0 + threadIdx.x < g.N) g.db_partial[(int64_t)split * g.N + n0 + threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 128];
   }
   float* out = g.partial + (int64_t)split * g.N * g.lddw;
 #pragma unroll
@@ -344,6 +362,14 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
       for (int p = 0; p < splits; ++p) s += partial[(int64_t)p * total + i];
     dW[i] = (accumulate ? dW[i] : 0.f) + s;
   }
+}
+
+__global__ __launch_bounds__(256) void bias_reduce_kernel(const float* __restrict__ partial, float* __restrict__ db, int N, int splits) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < splits; ++p) s += partial[(int64_t)p * N + n];
+  db[n] = s;
 }
 
 // out[n] = sum over primal rows (r % group == 0) of Z[r][n]; one workgroup per 64 columns x row-slice,
@@ -407,6 +433,7 @@ int sr_mlp_gemm_tn(const sr_gemm_tn_args* a, void* stream) {
   if (!a || !a->dW || !a->partial || a->R < 0 || a->N <= 0 || a->K <= 0 || a->splits < 1) return SR_EINVAL;
   if (a->R > 0 && (!a->Z || !a->A)) return SR_EINVAL;
   if ((a->ldz & 3) || (a->lda & 3) || ((uintptr_t)a->Z & 15) || ((uintptr_t)a->A & 15) || a->lddw < a->K) return SR_EINVAL;
+  if ((a->db != nullptr) != (a->db_partial != nullptr) || (a->db && a->group < 1)) return SR_EINVAL;
   const int tiles = (int)(sr_cdiv(a->N, 128) * sr_cdiv(a->K, 128));
   int rows_per_split = (int)sr_cdiv(a->R, a->splits);
   rows_per_split = (int)(sr_cdiv(rows_per_split, TBR) * TBR);
@@ -415,6 +442,9 @@ int sr_mlp_gemm_tn(const sr_gemm_tn_args* a, void* stream) {
   const int64_t total = (int64_t)a->N * a->lddw;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(sr_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, a->partial, a->dW,
                      a->N, a->K, a->lddw, a->R > 0 ? a->splits : 0, a->accumulate);
+  if (a->db && a->db_partial)
+    hipLaunchKernelGGL(bias_reduce_kernel, dim3((unsigned)sr_cdiv(a->N, 256)), dim3(256), 0, (hipStream_t)stream, a->db_partial, a->db,
+                       a->N, a->R > 0 ? a->splits : 0);
   return sr_launch_status();
 }
 

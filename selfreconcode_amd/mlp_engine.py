@@ -114,17 +114,19 @@ def _gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, group, act, mode, out_scale=
     _lib.call("sr_mlp_gemm_nt", ctypes.byref(a), _lib.stream_of(C))
 
 
-def _gemm_tn(Z, ldz, A, lda, R, N, K, lddw):
-    """dW [N, lddw] = Z[:, :N]^T A[:, :K] (deterministic slab reduction)."""
+def _gemm_tn(Z, ldz, A, lda, R, N, K, lddw, group=1):
+    """dW [N, lddw] = Z[:, :N]^T A[:, :K] and db [N] = sum of the primal rows of Z (deterministic slab reductions)."""
     splits = ctypes.c_int32(0)
     ws = _lib.raw("sr_mlp_gemm_tn_workspace_floats")(R, N, lddw, ctypes.byref(splits))
     dW = torch.empty((N, lddw), dtype=torch.float32, device=Z.device)
-    partial = torch.empty((max(int(ws), 1),), dtype=torch.float32, device=Z.device)
+    partial = torch.empty((max(int(ws), 1) + splits.value * N,), dtype=torch.float32, device=Z.device)
+    db = torch.empty((N,), dtype=torch.float32, device=Z.device)
     a = _lib.SrGemmTnArgs()
     a.Z, a.ldz, a.A, a.lda, a.dW, a.lddw, a.partial = _lib.ptr(Z), ldz, _lib.ptr(A), lda, _lib.ptr(dW), lddw, _lib.ptr(partial)
     a.R, a.N, a.K, a.splits, a.accumulate = R, N, K, splits.value, 0
+    a.db, a.db_partial, a.group = _lib.ptr(db), _lib.ptr(partial) + 4 * max(int(ws), 1), group
     _lib.call("sr_mlp_gemm_tn", ctypes.byref(a), _lib.stream_of(Z))
-    return dW
+    return dW, db
 
 
 def _colsum(Z, ldz, R, N, group):
@@ -171,8 +173,7 @@ def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_g
             L = spec.layers[l]
             X = A0 if l == 0 else acts[l - 1]
             if need_param_grad:
-                dWs[l] = _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K))
-                dbs[l] = _colsum(Zbar, Zbar.stride(0), R, L.N, group)
+                dWs[l], dbs[l] = _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group)
             if l > 0:
                 Pv = spec.layers[l - 1]
                 Znew = torch.empty((R, pad4(L.K)), dtype=torch.float32, device=A0.device)
@@ -246,7 +247,7 @@ class MLPCoreBackward(torch.autograd.Function):
         Ws, bs, acts = list(rest[:nl]), list(rest[nl:2 * nl]), list(rest[2 * nl:])
         NL = spec.layers[-1].N
         yb = pad_cols(ybar, pad4(NL))
-        WTs = [transpose_padded(Ws[l], spec.layers[l].K) for l in range(nl)]
+        WTs = [transposed_of(Ws[l], spec.layers[l].K) for l in range(nl)]
         A0bar, dWs, dbs = reverse(spec, A0, WTs, acts, yb, 1, need_in, need_par)
         ctx.spec = spec
         ctx.save_for_backward(A0, ybar, *Ws, *bs)
@@ -276,7 +277,7 @@ class MLPCoreBackward(torch.autograd.Function):
         ydot = acts2[-1].view(R, 2, -1)[:, 1, :NL]                     # d S / d ybar
         yb = pad_cols(ybar, pad4(NL))
         ybi = interleave([torch.zeros_like(yb), yb])                    # cotangent only on the tangent output
-        WTs = [transpose_padded(Ws[l], spec.layers[l].K) for l in range(nl)]
+        WTs = [transposed_of(Ws[l], spec.layers[l].K) for l in range(nl)]
         need_in = ctx.needs_input_grad[3]
         need_par = any(ctx.needs_input_grad[5:5 + 2 * nl])
         A0bar2, dWs, dbs = reverse(spec, A0i, WTs, acts2, ybi, 2, need_in, need_par)
@@ -284,6 +285,86 @@ class MLPCoreBackward(torch.autograd.Function):
         if gA0 is not None and gA0.shape[1] != A0.shape[1]:
             gA0 = pad_cols(gA0[:, :spec.K0], A0.shape[1])
         return (None, None, None, gA0, ydot.contiguous()) + tuple(dWs) + tuple(dbs) + (None,) * (nl - 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# Effective-weight packing with a per-parameter-version cache.  The reference recomputes
+# W = g v/|v| in a forward pre-hook at EVERY module call (~30 calls per iteration); here the padded weight
+# and its transpose are built once per optimizer step and handed out as aliases (no kernel launch on a hit),
+# while each use still back-propagates into (g, v) through its own autograd node.
+_PACK_CACHE = {}     # key: id(param) -> dict(sig=..., W=..., WT=..., norms=...)
+_WT_BY_PTR = {}      # data_ptr of a packed W -> its transposed copy
+
+
+def _sig(*ts):
+    return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in ts)
+
+
+def _pack_entry(key, sig, build):
+    e = _PACK_CACHE.get(key)
+    if e is None or e["sig"] != sig:
+        if e is not None:
+            _WT_BY_PTR.pop(e["W"].data_ptr(), None)
+        e = build()
+        e["sig"] = sig
+        _PACK_CACHE[key] = e
+        _WT_BY_PTR[e["W"].data_ptr()] = e["WT"]
+    return e
+
+
+class PackWeightNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, g):
+        K = v.shape[1]
+
+        def build():
+            with torch.no_grad():
+                w, norms = torch._weight_norm_interface(v, g, 0)
+                W = pad_cols(w, pad4(K)).contiguous()
+                return {"W": W, "WT": transpose_padded(W, K), "norms": norms}
+        e = _pack_entry(id(v), _sig(v, g), build)
+        ctx.save_for_backward(v, g, e["norms"])
+        return e["W"].detach()
+
+    @staticmethod
+    def backward(ctx, gW):
+        v, g, norms = ctx.saved_tensors
+        gv, gg = torch.ops.aten._weight_norm_interface_backward(gW[:, :v.shape[1]].contiguous(), v, g, norms, 0)
+        return gv, gg
+
+
+class PackPlain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w):
+        K = w.shape[1]
+
+        def build():
+            with torch.no_grad():
+                W = pad_cols(w, pad4(K)).contiguous()
+                if W.data_ptr() == w.data_ptr():
+                    W = W.clone()
+                return {"W": W, "WT": transpose_padded(W, K), "norms": None}
+        e = _pack_entry(id(w), _sig(w), build)
+        ctx.K = K
+        return e["W"].detach()
+
+    @staticmethod
+    def backward(ctx, gW):
+        return gW[:, :ctx.K]
+
+
+def pack_linear(lin):
+    """Padded effective weight of an nn.Linear, weight-normed (network.py:65-66) or plain."""
+    if hasattr(lin, "weight_g"):
+        return PackWeightNorm.apply(lin.weight_v, lin.weight_g)
+    return PackPlain.apply(lin.weight)
+
+
+def transposed_of(W, K):
+    WT = _WT_BY_PTR.get(W.data_ptr())
+    if WT is not None and WT.shape == (K, pad4(W.shape[0])):
+        return WT
+    return transpose_padded(W, K)
 
 
 def mlp_apply(spec, A0, Ws, bs):

@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from .Embedder import embed_rows
-from ..mlp_engine import MLPSpec, mlp_apply, pad_cols, pad4
+from ..mlp_engine import MLPSpec, mlp_apply, pad_cols, pad4, pack_linear
 from ..utils.utils import resolve_band_weights
 
 
@@ -50,7 +50,7 @@ class MLPTranslator(nn.Module):
         Ws, bs = [], []
         for l, L in enumerate(self.spec.layers):
             lin = getattr(self, "lin" + str(l))
-            Ws.append(pad_cols(lin.weight, pad4(L.K)))
+            Ws.append(pack_linear(lin))
             bs.append(lin.bias)
         return Ws, bs
 
@@ -58,12 +58,13 @@ class MLPTranslator(nn.Module):
         ratio = kwargs['ratio']['deformerRatio']
         ws = resolve_band_weights(self.multires, ratio)
         if batch_inds is not None:
-            flat, index = ps, batch_inds
+            flat, index, seg = ps, batch_inds, 0
         else:                                        # [N, V, 3] with one code per frame
             nb, nv = ps.shape[0], ps.shape[1]
             flat = ps.reshape(-1, 3)
             index = torch.arange(nb, device=ps.device).repeat_interleave(nv)
-        A0 = embed_rows(flat, self.multires, ws, extra=conds.reshape(-1, self.feature_vector_size), extra_index=index)
+            seg = nv
+        A0 = embed_rows(flat, self.multires, ws, extra=conds.reshape(-1, self.feature_vector_size), extra_index=index, segment=seg)
         Ws, bs = self.packed_weights()
         x = mlp_apply(self.spec, A0, Ws, bs)
         if batch_inds is not None:
@@ -226,7 +227,16 @@ class LBSkinner(nn.Module):
         if not needs_graph:
             y, _ = self.fused(ps, A, trans, batch_inds, False, None if tps is ps else tps)
             return y
-        # differentiable composition (any order): sampler (HIP fwd/bwd/dbwd) -> blend
+        if tps is ps:
+            flat = ps.reshape(-1, 3)
+            ppf = 0 if batch_inds is not None else ps.shape[1]
+            y = _FusedLBS.apply(self, flat, A, trans, batch_inds, ppf)
+            return y.view(ps.shape)
+        return self._composite(ps, tps, A, trans, batch_inds)
+
+    def _composite(self, ps, tps, A, trans, batch_inds):
+        """Differentiable composition (any derivative order): sampler (HIP fwd/bwd/dbwd) -> blend in torch ops."""
+        batch_size = A.shape[0]
         nps = 2. * (tps.reshape(-1, 3) - self.b_min) / (self.b_max - self.b_min) - 1.
         w = GridSamplerMine3dFunction.apply(self.ws, nps.reshape(1, 1, 1, -1, 3)).view(24, -1).transpose(0, 1)   # [P,24]
         A12 = A[:, :, :3, :].reshape(batch_size, 24, 12)
@@ -239,3 +249,52 @@ class LBSkinner(nn.Module):
         Tall = (w @ A12.permute(1, 0, 2).reshape(24, batch_size * 12)).view(-1, batch_size, 12)
         T = torch.gather(Tall, 1, batch_inds.view(-1, 1, 1).expand(-1, 1, 12)).view(-1, 3, 4)
         return (T[..., :3] @ p.unsqueeze(-1)).squeeze(-1) + T[..., 3] + trans[batch_inds]
+
+    def fused_backward(self, flat, A, batch_inds, ppf, ybar, need_p, need_A, need_t):
+        P = flat.shape[0]
+        a = _lib.SrLbsArgs()
+        A12 = A[:, :, :3, :].contiguous()
+        vol = self.ws.permute(0, 2, 3, 4, 1)
+        a.p, a.tp, a.P = _lib.ptr(flat), 0, P
+        a.A, a.trans, a.nframes = _lib.ptr(A12), 0, A.shape[0]
+        a.batch_inds, a.points_per_frame = _lib.ptr(batch_inds), ppf
+        a.vol, a.D, a.H, a.W = _lib.ptr(vol), vol.shape[1], vol.shape[2], vol.shape[3]
+        for i in range(3):
+            a.bmin[i], a.bmax[i] = self._box[0][i], self._box[1][i]
+        yb = ybar.contiguous().float()
+        pbar = torch.empty_like(flat) if need_p else None
+        Abar = torch.zeros((A.shape[0], 24, 12), device=flat.device) if need_A else None
+        tbar = torch.zeros((A.shape[0], 3), device=flat.device) if need_t else None
+        with torch.cuda.device(flat.device):
+            _lib.call("sr_lbs_bwd", ctypes.byref(a), _lib.ptr(yb), _lib.ptr(pbar), _lib.ptr(Abar), _lib.ptr(tbar), _lib.stream_of(flat))
+        return pbar, Abar, tbar
+
+
+class _FusedLBS(torch.autograd.Function):
+    """y = LBS(p; A, trans) with one fused kernel forward and one backward.  When the backward itself has to be
+    differentiated (create_graph=True: Jacobian-based losses) it falls back to the differentiable composition."""
+
+    @staticmethod
+    def forward(ctx, skin, flat, A, trans, batch_inds, ppf):
+        flat = flat.contiguous()
+        y, _ = skin.fused(flat if batch_inds is not None else flat.view(A.shape[0], -1, 3), A, trans, batch_inds, False, None)
+        ctx.skin, ctx.ppf = skin, ppf
+        ctx.save_for_backward(flat, A, trans, batch_inds)
+        return y.reshape(-1, 3)
+
+    @staticmethod
+    def backward(ctx, ybar):
+        flat, A, trans, batch_inds = ctx.saved_tensors
+        skin = ctx.skin
+        need_p, need_A, need_t = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        if torch.is_grad_enabled():
+            ps = flat if batch_inds is not None else flat.view(A.shape[0], -1, 3)
+            y2 = skin._composite(ps, ps, A, trans, batch_inds).reshape(-1, 3)
+            ins = [t for t, n in ((flat, need_p), (A, need_A), (trans, need_t)) if n]
+            gs = list(torch.autograd.grad(y2, ins, ybar, create_graph=True, allow_unused=True))
+            out = [gs.pop(0) if n else None for n in (need_p, need_A, need_t)]
+            return None, out[0], out[1], out[2], None, None
+        pbar, Abar, tbar = skin.fused_backward(flat, A, batch_inds, ctx.ppf, ybar, need_p, need_A, need_t)
+        if Abar is not None:
+            Abar = torch.nn.functional.pad(Abar.view(A.shape[0], 24, 3, 4), (0, 0, 0, 1))
+        return None, pbar, Abar, tbar, None, None

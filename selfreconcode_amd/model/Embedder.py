@@ -26,7 +26,7 @@ class PEFunction(torch.autograd.Function):
     of A0), so any derivative order works."""
 
     @staticmethod
-    def forward(ctx, x, wt, L, extra, extra_index):
+    def forward(ctx, x, wt, L, extra, extra_index, segment=0):
         _lib.require_gpu(x)
         x = x.contiguous().float()
         P = x.shape[0]
@@ -37,7 +37,7 @@ class PEFunction(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _lib.call("sr_pe_embed", _lib.ptr(x), P, L, _lib.ptr(wt), _lib.ptr(ex), 0 if ex is None else ex.stride(0), E,
                       _lib.ptr(extra_index), 1, _lib.ptr(out), ldo, _lib.stream_of(x))
-        ctx.L, ctx.E = L, E
+        ctx.L, ctx.E, ctx.segment = L, E, segment
         ctx.n_extra = 0 if extra is None else extra.shape[0]
         ctx.save_for_backward(out, extra_index)
         return out
@@ -58,17 +58,19 @@ class PEFunction(torch.autograd.Function):
             ge = g[:, 3 + 6 * L:3 + 6 * L + E]
             if extra_index is None:
                 gextra = ge
+            elif ctx.segment:                       # rows of one frame are contiguous: plain segmented sum, no atomics
+                gextra = ge.reshape(ctx.n_extra, ctx.segment, E).sum(1)
             else:
                 gextra = torch.zeros((ctx.n_extra, E), dtype=g.dtype, device=g.device).index_add(0, extra_index, ge)
-        return gx, None, None, gextra, None
+        return gx, None, None, gextra, None, None
 
 
-def embed_rows(x, multires, ws=None, extra=None, extra_index=None):
+def embed_rows(x, multires, ws=None, extra=None, extra_index=None, segment=0):
     """First-layer input rows [P, pad4(3 + 6*multires + E)] (fused PE + concat)."""
     if ws is not None and any(float(ws[2 * k]) != float(ws[2 * k + 1]) for k in range(multires)):
         raise NotImplementedError("fused embedder needs equal (sin, cos) weights per band, as utils.annealing_weights yields")
     wt, _ = band_weight_tensor(ws, multires, x.device)
-    return PEFunction.apply(x, wt, multires, extra, extra_index)
+    return PEFunction.apply(x, wt, multires, extra, extra_index, segment)
 
 
 class Embedder:

@@ -5,7 +5,7 @@ import torch.nn as nn
 
 from .Embedder import embed_rows
 from .network import effective_weight
-from ..mlp_engine import MLPSpec, mlp_apply, pad_cols, pad4
+from ..mlp_engine import MLPSpec, mlp_apply, pad_cols, pad4, pack_linear
 from ..utils.utils import resolve_band_weights
 
 
@@ -35,7 +35,7 @@ class RenderingNetwork_view_norm(nn.Module):
         Ws, bs = [], []
         for l, L in enumerate(self.spec.layers):
             lin = getattr(self, "lin" + str(l))
-            Ws.append(pad_cols(effective_weight(lin), pad4(L.K)))
+            Ws.append(pack_linear(lin))
             bs.append(lin.bias)
         return torch.tanh(mlp_apply(self.spec, x, Ws, bs))
 
