@@ -47,7 +47,7 @@ def test_mc_closed_surface_properties_and_iso():
     e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]); e.sort(1)
     u, c = np.unique(e, axis=0, return_counts=True)
     assert (c == 2).all() and f.min() >= 0                              # closed 2-manifold, no dangling -1
-    assert len(verts) - len(u) + len(f) == 4                           # two spheres: Euler characteristic 2 + 2
+    assert len(verts) - len(u) + len(f) == 2                           # the two blobs overlap: one closed genus-0 surface
 
 
 def test_mc_error_convention_and_empty():
