@@ -138,6 +138,10 @@ int sr_colsum_rows(const float* Z, int64_t ldz, int32_t R, int32_t N, int32_t gr
  * group == 4 also writes the three d/dx_t seed-tangent rows.  band_weights: 2*L floats (device). */
 int sr_pe_embed(const float* x, int64_t P, int32_t L, const float* band_weights, const float* extra, int64_t ldextra,
                 int32_t E, const int64_t* extra_index /*nullable*/, int32_t group, float* out, int64_t ldo, void* stream);
+/* Reverse of sr_pe_embed w.r.t. x: gA0 = cotangent of the embed rows (same row layout, pitch ldg) -> xbar [P,3].
+ * Covers the second-derivative term of the group-4 seed-tangent rows. */
+int sr_pe_embed_bwd(const float* x, int64_t P, int32_t L, const float* band_weights, int32_t group, const float* gA0,
+                    int64_t ldg, float* xbar, void* stream);
 
 /* ---------------------------------------------------------------- fused LBS (a5, a8/a9 LBS part)
  * Replaces, for the no-autograd callers (ray refiner, inference), LBSkinner.forward's

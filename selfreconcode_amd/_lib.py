@@ -80,6 +80,7 @@ SIGNATURES = {
     "sr_svd3x3": [_vp, _i64, _vp, _vp, _vp, _vp],
     "sr_splat_fwd": [_vp, _vp, _i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp],
     "sr_splat_bwd": [_vp, _vp, _i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp, _vp],
+    "sr_pe_embed_bwd": [_vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _i64, _vp, _vp],
     "sr_pe_embed": [_vp, _i64, ctypes.c_int32, _vp, _vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _i64, _vp],
 }
 _RESTYPE = {"sr_mlp_gemm_tn_workspace_floats": _i64, "sr_mc_workspace_bytes": _i64}

@@ -512,3 +512,40 @@ extern "C" int sr_pe_embed(const float* x, int64_t P, int32_t L, const float* ba
                      extra, ldextra, E, extra_index, group, out, ldo);
   return sr_launch_status();
 }
+
+// Reverse of sr_pe_embed with respect to x: xbar[p,c] = A0bar[primal, c] + sum_k 2^k (w cos . g_sin - w sin . g_cos)
+//   (+ for group 4: tangent row t == c only, since the encoding is separable per coordinate:
+//      A0bar[t, sin block] * (-w 4^k sin) + A0bar[t, cos block] * (-w 4^k cos) ).
+namespace {
+__global__ __launch_bounds__(256) void pe_embed_bwd_kernel(const float* __restrict__ x, int64_t P, int L, const float* __restrict__ w,
+                                                            int group, const float* __restrict__ gA0, int64_t ldg, float* __restrict__ xbar) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P * 3; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / 3;
+    const int c = (int)(i % 3);
+    const float xv = x[i];
+    const float* g0 = gA0 + (p * group) * ldg;
+    const float* gt = group == 4 ? gA0 + (p * 4 + 1 + c) * ldg : nullptr;
+    float acc = g0[c];
+    for (int k = 0; k < L; ++k) {
+      const float f = (float)(1 << k);
+      float sn, cs;
+      sincosf(xv * f, &sn, &cs);
+      const float ws = w[2 * k], wc = w[2 * k + 1];
+      const int is = 3 + 6 * k + c, ic = is + 3;
+      acc += f * (ws * cs * g0[is] - wc * sn * g0[ic]);
+      if (gt) acc -= f * f * (ws * sn * gt[is] + wc * cs * gt[ic]);
+    }
+    xbar[i] = acc;
+  }
+}
+}  // namespace
+
+extern "C" int sr_pe_embed_bwd(const float* x, int64_t P, int32_t L, const float* band_weights, int32_t group, const float* gA0,
+                               int64_t ldg, float* xbar, void* stream) {
+  if (P < 0 || L < 0 || L > 16 || (group != 1 && group != 4) || ldg < 3 + 6 * L) return SR_EINVAL;
+  if (P == 0) return SR_OK;
+  if (!x || !gA0 || !xbar || (L > 0 && !band_weights)) return SR_EINVAL;
+  hipLaunchKernelGGL(pe_embed_bwd_kernel, dim3(sr_stream_grid(P * 3, 256)), dim3(256), 0, (hipStream_t)stream, x, P, L, band_weights,
+                     group, gA0, ldg, xbar);
+  return sr_launch_status();
+}

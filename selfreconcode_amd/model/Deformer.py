@@ -298,3 +298,83 @@ class _FusedLBS(torch.autograd.Function):
         if Abar is not None:
             Abar = torch.nn.functional.pad(Abar.view(A.shape[0], 24, 3, 4), (0, 0, 0, 1))
         return None, pbar, Abar, tbar, None, None
+
+
+class TranslatorValueJacobian(torch.autograd.Function):
+    """(d, J) = (p + offset(p), I + d offset / d p) of the deformation MLP by FORWARD mode: one group-4 pass of
+    the layer kernels (primal + 3 seed tangents per point) instead of a forward plus three reverse passes
+    (utils/utils.py:106-120), and ONE group-4 reverse sweep as its backward instead of reverse-over-reverse.
+    First-order differentiable (what the deformation regulariser needs, network.py:565-582)."""
+
+    @staticmethod
+    def forward(ctx, tr, ratio, x, conds, index, segment, *wb):
+        from .. import mlp_engine as me
+        from .Embedder import band_weight_tensor
+        nl = len(tr.spec.layers)
+        Ws, bs = list(wb[:nl]), list(wb[nl:])
+        flat = x.reshape(-1, 3).contiguous().float()
+        P = flat.shape[0]
+        wt, _ = band_weight_tensor(resolve_band_weights(tr.multires, ratio), tr.multires, flat.device)
+        E = tr.feature_vector_size
+        ldo = me.pad4(3 + 6 * tr.multires + E)
+        A0 = torch.empty((P * 4, ldo), dtype=torch.float32, device=flat.device)
+        cd = conds.reshape(-1, E).contiguous().float()
+        with torch.cuda.device(flat.device):
+            _lib.call("sr_pe_embed", _lib.ptr(flat), P, tr.multires, _lib.ptr(wt), _lib.ptr(cd), cd.stride(0), E, _lib.ptr(index), 4,
+                      _lib.ptr(A0), ldo, _lib.stream_of(flat))
+            acts = me.forward(tr.spec, A0, Ws, bs, 4)
+        out = acts[-1].view(P, 4, -1)[:, :, :3]
+        d = flat + out[:, 0]
+        J = out[:, 1:4].transpose(1, 2) + torch.eye(3, device=flat.device)         # J[p, r, c] = delta + d off_r / d x_c
+        ctx.tr, ctx.wt, ctx.segment, ctx.n_extra = tr, wt, segment, cd.shape[0]
+        ctx.save_for_backward(flat, index, A0, *wb, *acts[:-1])
+        return d.view(x.shape), J
+
+    @staticmethod
+    def backward(ctx, dbar, Jbar):
+        from .. import mlp_engine as me
+        tr = ctx.tr
+        nl = len(tr.spec.layers)
+        saved = ctx.saved_tensors
+        flat, index, A0 = saved[0], saved[1], saved[2]
+        wb, acts = saved[3:3 + 2 * nl], list(saved[3 + 2 * nl:])
+        Ws = list(wb[:nl])
+        P = flat.shape[0]
+        ybar = torch.zeros((P, 4, 4), dtype=torch.float32, device=flat.device)
+        if dbar is not None:
+            ybar[:, 0, :3] = dbar.reshape(-1, 3)
+        if Jbar is not None:
+            ybar[:, 1:4, :3] = Jbar.transpose(1, 2)
+        WTs = [me.transposed_of(Ws[l], tr.spec.layers[l].K) for l in range(nl)]
+        acts_full = acts + [None]
+        need_par = any(ctx.needs_input_grad[6:])
+        A0bar, dWs, dbs = me.reverse(tr.spec, A0, WTs, acts_full, ybar.view(P * 4, 4), 4, True, need_par)
+        if not need_par:
+            dWs, dbs = [None] * nl, [None] * nl
+        xbar = torch.empty_like(flat)
+        with torch.cuda.device(flat.device):
+            _lib.call("sr_pe_embed_bwd", _lib.ptr(flat), P, tr.multires, _lib.ptr(ctx.wt), 4, _lib.ptr(A0bar), A0bar.stride(0),
+                      _lib.ptr(xbar), _lib.stream_of(flat))
+        if dbar is not None:
+            xbar = xbar + dbar.reshape(-1, 3)
+        gcond = None
+        if ctx.needs_input_grad[3]:
+            E = tr.feature_vector_size
+            ge = A0bar.view(P, 4, -1)[:, 0, 3 + 6 * tr.multires:3 + 6 * tr.multires + E]
+            if ctx.segment:
+                gcond = ge.reshape(ctx.n_extra, ctx.segment, E).sum(1)
+            else:
+                gcond = torch.zeros((ctx.n_extra, E), device=flat.device).index_add(0, index, ge)
+        return (None, None, xbar, gcond, None, None) + tuple(dWs) + tuple(dbs)
+
+
+def translator_value_jacobian(tr, ps, conds, batch_inds, ratio):
+    """ps [P,3] with batch_inds, or [N,V,3] (one code per frame).  Returns d (like ps) and J [P,3,3]."""
+    r = ratio['deformerRatio'] if isinstance(ratio, dict) else ratio
+    if batch_inds is not None:
+        index, seg = batch_inds, 0
+    else:
+        index = torch.arange(ps.shape[0], device=ps.device).repeat_interleave(ps.shape[1])
+        seg = ps.shape[1]
+    Ws, bs = tr.packed_weights()
+    return TranslatorValueJacobian.apply(tr, r, ps, conds, index, seg, *Ws, *bs)

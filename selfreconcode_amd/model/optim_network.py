@@ -215,9 +215,8 @@ class OptimNetwork(nn.Module):
         if noise_local is None:
             noise_local = torch.randn_like(pts)
         pts = torch.cat([pts, pts + noise_local * 0.01], dim=0).view(1, -1, 3).expand(N, -1, 3)
-        pts = pts.contiguous().requires_grad_()
-        defVs = self.deformer.defs[0](pts, d_cond, ratio=ratio)
-        Jacobs = U.compute_Jacobian(pts, defVs, True, True)
+        from .Deformer import translator_value_jacobian
+        _, Jacobs = translator_value_jacobian(self.deformer.defs[0], pts.contiguous(), d_cond, None, ratio)   # forward-mode Jacobian
         s = torch.log(singular_values_3x3(Jacobs))
         return U.GMRobustError((s * s).sum(1), self.conf.get_float('def_regu.c'), True).mean()
 

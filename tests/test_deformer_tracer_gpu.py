@@ -117,3 +117,31 @@ def test_optimize_surface_ps_golden(golden):
     close(ps, g["ps"], rtol=0, atol=2e-5)
     agree = (ok.cpu() == g["ok"]).float().mean()
     assert agree > 0.95, agree
+
+
+def test_translator_forward_mode_jacobian_and_its_reverse():
+    """group-4 forward-mode (d, J) == autograd Jacobian of the oracle; gradients of a loss on (d, J) w.r.t. weights,
+    per-frame codes and points == the oracle's reverse-over-reverse."""
+    from selfreconcode_amd.model.Deformer import MLPTranslator, translator_value_jacobian
+    tr = MLPTranslator(128, 6).to(DEV)
+    sd = fx.det_params(fx.DEF_SPEC, 11)
+    tr.load_state_dict(sd, strict=True)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ps = fx.det_tensor((3, 21, 3), 1, 0.7); conds = fx.det_tensor((3, 128), 2, 0.1)
+    cd, cj = fx.det_tensor((3, 21, 3), 3, 1.0), fx.det_tensor((63, 3, 3), 4, 1.0)
+    po = ps.clone().requires_grad_(True); co = conds.clone().requires_grad_(True)
+    do, _ = orc.translator_forward(sdo, po, co, None, RATIO)
+    Jo = orc.compute_jacobian(po, do, True, True)
+    ref = torch.autograd.grad((do * cd).sum() + (Jo * cj).sum(), [po, co, sdo["lin0.weight"], sdo["lin2.weight"], sdo["lin4.bias"], sdo["lin1.bias"]])
+    pg = ps.to(DEV).requires_grad_(True); cg = conds.to(DEV).requires_grad_(True)
+    d, J = translator_value_jacobian(tr, pg, cg, None, RATIO)
+    close(d, do, atol=2e-6); close(J, Jo, 1e-4, 1e-5)
+    ours = torch.autograd.grad((d * cd.to(DEV)).sum() + (J * cj.to(DEV)).sum(), [pg, cg, tr.lin0.weight, tr.lin2.weight, tr.lin4.bias, tr.lin1.bias])
+    for a, b in zip(ours, ref):
+        close(a, b, 1e-3, 1e-4 * max(1.0, float(b.abs().max())))
+    # ray mode (batch_inds)
+    bi = torch.arange(30) % 3
+    p2 = fx.det_tensor((30, 3), 5, 0.6)
+    d2o, _ = orc.translator_forward(sdo, p2, conds, bi, RATIO)
+    d2, J2 = translator_value_jacobian(tr, p2.to(DEV), conds.to(DEV), bi.to(DEV), RATIO)
+    close(d2, d2o, atol=2e-6)
