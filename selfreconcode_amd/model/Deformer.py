@@ -326,7 +326,7 @@ class TranslatorValueJacobian(torch.autograd.Function):
         out = acts[-1].view(P, 4, -1)[:, :, :3]
         d = flat + out[:, 0]
         J = out[:, 1:4].transpose(1, 2) + torch.eye(3, device=flat.device)         # J[p, r, c] = delta + d off_r / d x_c
-        ctx.tr, ctx.wt, ctx.segment, ctx.n_extra = tr, wt, segment, cd.shape[0]
+        ctx.tr, ctx.wt, ctx.segment, ctx.n_extra, ctx.xshape = tr, wt, segment, cd.shape[0], x.shape
         ctx.save_for_backward(flat, index, A0, *wb, *acts[:-1])
         return d.view(x.shape), J
 
@@ -365,7 +365,7 @@ class TranslatorValueJacobian(torch.autograd.Function):
                 gcond = ge.reshape(ctx.n_extra, ctx.segment, E).sum(1)
             else:
                 gcond = torch.zeros((ctx.n_extra, E), device=flat.device).index_add(0, index, ge)
-        return (None, None, xbar, gcond, None, None) + tuple(dWs) + tuple(dbs)
+        return (None, None, xbar.view(ctx.xshape), gcond, None, None) + tuple(dWs) + tuple(dbs)
 
 
 def translator_value_jacobian(tr, ps, conds, batch_inds, ratio):
