@@ -42,6 +42,7 @@ def main():
     FRAMES_PER_RANK, RAYS = 3, 2048
     net, ds, conf = build_synthetic_scene(device=device, frame_num=64 if world <= 8 else 8 * world)
     params = [p for p in net.parameters() if p.requires_grad]
+    mlp_engine.set_deferred_param_grads(True)              # one weight-norm backward + grad add per layer per step
     opt = torch.optim.Adam([{'params': ds.learnable_weights()}, {'params': params}], lr=conf.get_float('train.learning_rate'))
     bucket = srdist.GradBucket(list(ds.learnable_weights()) + params)
     ratio_of = lambda it: {'sdfRatio': 1., 'deformerRatio': it / 2500. + 0.5, 'renderRatio': 1.}

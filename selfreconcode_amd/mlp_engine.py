@@ -114,16 +114,18 @@ def _gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, group, act, mode, out_scale=
     _lib.call("sr_mlp_gemm_nt", ctypes.byref(a), _lib.stream_of(C))
 
 
-def _gemm_tn(Z, ldz, A, lda, R, N, K, lddw, group=1):
-    """dW [N, lddw] = Z[:, :N]^T A[:, :K] and db [N] = sum of the primal rows of Z (deterministic slab reductions)."""
+def _gemm_tn(Z, ldz, A, lda, R, N, K, lddw, group=1, dW=None, db=None, accumulate=False):
+    """dW [N, lddw] (+)= Z[:, :N]^T A[:, :K] and db [N] (+)= sum of the primal rows of Z (deterministic slab reductions)."""
     splits = ctypes.c_int32(0)
     ws = _lib.raw("sr_mlp_gemm_tn_workspace_floats")(R, N, lddw, ctypes.byref(splits))
-    dW = torch.empty((N, lddw), dtype=torch.float32, device=Z.device)
+    if dW is None:
+        dW = torch.empty((N, lddw), dtype=torch.float32, device=Z.device)
     partial = torch.empty((max(int(ws), 1) + splits.value * N,), dtype=torch.float32, device=Z.device)
-    db = torch.empty((N,), dtype=torch.float32, device=Z.device)
+    if db is None:
+        db = torch.empty((N,), dtype=torch.float32, device=Z.device)
     a = _lib.SrGemmTnArgs()
     a.Z, a.ldz, a.A, a.lda, a.dW, a.lddw, a.partial = _lib.ptr(Z), ldz, _lib.ptr(A), lda, _lib.ptr(dW), lddw, _lib.ptr(partial)
-    a.R, a.N, a.K, a.splits, a.accumulate = R, N, K, splits.value, 0
+    a.R, a.N, a.K, a.splits, a.accumulate = R, N, K, splits.value, 1 if accumulate else 0
     a.db, a.db_partial, a.group = _lib.ptr(db), _lib.ptr(partial) + 4 * max(int(ws), 1), group
     _lib.call("sr_mlp_gemm_tn", ctypes.byref(a), _lib.stream_of(Z))
     return dW, db
@@ -158,7 +160,7 @@ def forward(spec, A0, Ws, bs, group):
     return acts
 
 
-def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_grad=True):
+def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_grad=True, Ws=None, bs=None):
     """One reverse sweep.  Ybar [R, >= N_L] (pitch % 4): cotangent of the output rows.  WTs[l] = W_l^T as
     [K_l, pad4(N_l)].  Returns (A0bar [R, pad4(K0)] or None, dWs [N_l, pad4(K_l)], dbs [N_l])."""
     _check_mat(Ybar, "Ybar")
@@ -173,7 +175,11 @@ def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_g
             L = spec.layers[l]
             X = A0 if l == 0 else acts[l - 1]
             if need_param_grad:
-                dWs[l], dbs[l] = _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group)
+                sink = _deferred_sink(Ws[l], bs[l]) if (DEFERRED_PARAM_GRADS and Ws is not None) else None
+                if sink is not None:          # accumulate straight into the per-step gradient buffers (no autograd traffic)
+                    _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group, dW=sink[0], db=sink[1], accumulate=True)
+                else:
+                    dWs[l], dbs[l] = _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group)
             if l > 0:
                 Pv = spec.layers[l - 1]
                 Znew = torch.empty((R, pad4(L.K)), dtype=torch.float32, device=A0.device)
@@ -248,7 +254,7 @@ class MLPCoreBackward(torch.autograd.Function):
         NL = spec.layers[-1].N
         yb = pad_cols(ybar, pad4(NL))
         WTs = [transposed_of(Ws[l], spec.layers[l].K) for l in range(nl)]
-        A0bar, dWs, dbs = reverse(spec, A0, WTs, acts, yb, 1, need_in, need_par)
+        A0bar, dWs, dbs = reverse(spec, A0, WTs, acts, yb, 1, need_in, need_par, Ws, bs)
         ctx.spec = spec
         ctx.save_for_backward(A0, ybar, *Ws, *bs)
         ctx.set_materialize_grads(False)
@@ -280,7 +286,7 @@ class MLPCoreBackward(torch.autograd.Function):
         WTs = [transposed_of(Ws[l], spec.layers[l].K) for l in range(nl)]
         need_in = ctx.needs_input_grad[3]
         need_par = any(ctx.needs_input_grad[5:5 + 2 * nl])
-        A0bar2, dWs, dbs = reverse(spec, A0i, WTs, acts2, ybi, 2, need_in, need_par)
+        A0bar2, dWs, dbs = reverse(spec, A0i, WTs, acts2, ybi, 2, need_in, need_par, Ws, bs)
         gA0 = A0bar2.view(R, 2, -1)[:, 0, :] if A0bar2 is not None else None
         if gA0 is not None and gA0.shape[1] != A0.shape[1]:
             gA0 = pad_cols(gA0[:, :spec.K0], A0.shape[1])
@@ -305,10 +311,16 @@ def _pack_entry(key, sig, build):
     if e is None or e["sig"] != sig:
         if e is not None:
             _WT_BY_PTR.pop(e["W"].data_ptr(), None)
+        if e is not None and e.get("dirty"):
+            raise RuntimeError("mlp_engine: parameters changed while deferred gradients were pending; call flush_param_grads() "
+                               "before the optimizer step")
+        if e is not None:
+            _ENTRY_BY_PTR.pop(e["W"].data_ptr(), None)
         e = build()
         e["sig"] = sig
         _PACK_CACHE[key] = e
         _WT_BY_PTR[e["W"].data_ptr()] = e["WT"]
+        _ENTRY_BY_PTR[e["W"].data_ptr()] = e
     return e
 
 
@@ -323,11 +335,14 @@ class PackWeightNorm(torch.autograd.Function):
                 W = pad_cols(w, pad4(K)).contiguous()
                 return {"W": W, "WT": transpose_padded(W, K), "norms": norms}
         e = _pack_entry(id(v), _sig(v, g), build)
+        e["src"] = (v, g)
         ctx.save_for_backward(v, g, e["norms"])
         return e["W"].detach()
 
     @staticmethod
     def backward(ctx, gW):
+        if gW is None:
+            return None, None
         v, g, norms = ctx.saved_tensors
         gv, gg = torch.ops.aten._weight_norm_interface_backward(gW[:, :v.shape[1]].contiguous(), v, g, norms, 0)
         return gv, gg
@@ -345,12 +360,13 @@ class PackPlain(torch.autograd.Function):
                     W = W.clone()
                 return {"W": W, "WT": transpose_padded(W, K), "norms": None}
         e = _pack_entry(id(w), _sig(w), build)
+        e["src"] = (w,)
         ctx.K = K
         return e["W"].detach()
 
     @staticmethod
     def backward(ctx, gW):
-        return gW[:, :ctx.K]
+        return None if gW is None else gW[:, :ctx.K]
 
 
 def pack_linear(lin):
@@ -365,6 +381,53 @@ def transposed_of(W, K):
     if WT is not None and WT.shape == (K, pad4(W.shape[0])):
         return WT
     return transpose_padded(W, K)
+
+
+# ------------------------------------------------------------------------------------------------
+# Deferred parameter gradients (opt-in, used by the training step): every weight-gradient GEMM adds
+# into ONE persistent buffer per layer instead of returning a tensor that autograd then pushes through
+# a weight-norm backward and an AccumulateGrad add for each of the ~30 network uses per iteration.
+# `flush_param_grads()` runs the weight-norm backward once per layer and adds into the parameters'
+# .grad; OptimNetwork.propagateTmpPsGrad (the last gradient producer of a step) calls it.
+DEFERRED_PARAM_GRADS = False
+_ENTRY_BY_PTR = {}
+
+
+def set_deferred_param_grads(flag):
+    global DEFERRED_PARAM_GRADS
+    flush_param_grads()
+    DEFERRED_PARAM_GRADS = bool(flag)
+
+
+def _deferred_sink(W, b):
+    e = _ENTRY_BY_PTR.get(W.data_ptr())
+    if e is None or b is None or not b.requires_grad:
+        return None
+    if e.get("dW") is None:
+        e["dW"] = torch.zeros_like(e["W"])
+    e["dirty"] = True
+    if b.grad is None:
+        b.grad = torch.zeros_like(b)
+    return e["dW"], b.grad
+
+
+def flush_param_grads():
+    for e in list(_PACK_CACHE.values()):
+        if not e.get("dirty"):
+            continue
+        dW = e["dW"]
+        src = e["src"]
+        if len(src) == 2:                                  # weight-normed: (v, g)
+            v, g = src
+            gv, gg = torch.ops.aten._weight_norm_interface_backward(dW[:, :v.shape[1]].contiguous(), v.detach(), g.detach(), e["norms"], 0)
+            v.grad = gv if v.grad is None else v.grad.add_(gv)
+            g.grad = gg if g.grad is None else g.grad.add_(gg)
+        else:
+            w = src[0]
+            gw = dW[:, :w.shape[1]]
+            w.grad = gw.clone() if w.grad is None else w.grad.add_(gw)
+        dW.zero_()
+        e["dirty"] = False
 
 
 def mlp_apply(spec, A0, Ws, bs):

@@ -348,7 +348,7 @@ class TranslatorValueJacobian(torch.autograd.Function):
         WTs = [me.transposed_of(Ws[l], tr.spec.layers[l].K) for l in range(nl)]
         acts_full = acts + [None]
         need_par = any(ctx.needs_input_grad[6:])
-        A0bar, dWs, dbs = me.reverse(tr.spec, A0, WTs, acts_full, ybar.view(P * 4, 4), 4, True, need_par)
+        A0bar, dWs, dbs = me.reverse(tr.spec, A0, WTs, acts_full, ybar.view(P * 4, 4), 4, True, need_par, Ws, list(wb[nl:]))
         if not need_par:
             dWs, dbs = [None] * nl, [None] * nl
         xbar = torch.empty_like(flat)

@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import dist as srdist
+from .. import mlp_engine
 from ..ext import MCGpu
 from ..ext.FastMinv import Fast3x3Minv
 from ..ops import singular_values_3x3, splat_silhouette
@@ -281,6 +282,7 @@ class OptimNetwork(nn.Module):
             loss = loss + consistent_loss * cw
         self.TmpOptimizer.zero_grad()
         loss.backward()
+        mlp_engine.flush_param_grads()       # last gradient producer of the step (no-op unless deferred mode is on)
         srdist.all_reduce_mean_(self.TmpVs.grad)     # shared template: exact batch semantics across ranks
         self.TmpOptimizer.step()
         mnfld_pred = self.sdf(self.TmpVs, ratio).view(-1)
@@ -294,6 +296,7 @@ class OptimNetwork(nn.Module):
         through the constraint system f(p) = 0, [v]x (d(p) - c) = 0 (network.py:702-814)."""
         if self.TmpPs is None or self.TmpPs.grad is None:
             self.info['invInfo'] = (-1, -1)
+            mlp_engine.flush_param_grads()
             return
         device = self.TmpPs.device
         poses, trans, d_cond, _ = self.dataset.get_grad_parameters(frame_ids, device)
@@ -312,17 +315,11 @@ class OptimNetwork(nn.Module):
         btb_inv, check = Fast3x3Minv(btb.contiguous())
         self.info['invInfo'] = (check.numel(), check.sum())
         rhs_1 = grad_l_p.view(-1, 1, 3).matmul(btb_inv.matmul(b.permute(0, 2, 1)))        # [P,1,4]
-        loss = 0.
-        params = [q for q in self.sdf.parameters() if q.requires_grad]
-        grads = torch.autograd.grad(self.sdf(p, ratio), params, -rhs_1[:, :, 0], allow_unused=True)
-        for q, g in zip(params, grads):
-            if g is not None:
-                loss = loss + (q * g).sum()
-        params = [q for q in self.deformer.parameters() if q.requires_grad]
-        d = self.deformer(p, defconds, self.batch_inds, ratio=ratio)
+        # The reference builds a surrogate loss sum(param * grad) from three autograd.grad calls and back-propagates it
+        # (network.py:773-814); that adds `grad` to every parameter's .grad, which is exactly one backward of
+        # (f, d) with the cotangents (-rhs_f, temp).
+        f2 = self.sdf(p.detach(), ratio)
+        d2 = self.deformer(p.detach(), defconds, self.batch_inds, ratio=ratio)
         temp = (rhs_1[:, :, -3:].matmul(-v_cross)).view(-1, 3)
-        grads = torch.autograd.grad(d, params + opt_defconds, temp, allow_unused=True)
-        for q, g in zip(params + opt_defconds, grads):
-            if g is not None:
-                loss = loss + (q * g).sum()
-        loss.backward()
+        torch.autograd.backward([f2, d2], [(-rhs_1[:, :, 0]).reshape(f2.shape).detach(), temp.detach()])
+        mlp_engine.flush_param_grads()       # last gradient producer of the step (no-op unless deferred mode is on)
