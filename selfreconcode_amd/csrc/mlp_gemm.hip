@@ -373,12 +373,13 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void bias_reduce_kernel(const float* __restrict__ partial, float* __restrict__ db, int N, int splits) {
+__global__ __launch_bounds__(256) void bias_reduce_kernel(const float* __restrict__ partial, float* __restrict__ db, int N, int splits,
+                                                           int accumulate) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float s = 0.f;
   for (int p = 0; p < splits; ++p) s += partial[(int64_t)p * N + n];
-  db[n] = s;
+  db[n] = (accumulate ? db[n] : 0.f) + s;
 }
 
 // out[n] = sum over primal rows (r % group == 0) of Z[r][n]; one workgroup per 64 columns x row-slice,
@@ -453,7 +454,7 @@ int sr_mlp_gemm_tn(const sr_gemm_tn_args* a, void* stream) {
                      a->N, a->K, a->lddw, a->R > 0 ? a->splits : 0, a->accumulate);
   if (a->db && a->db_partial)
     hipLaunchKernelGGL(bias_reduce_kernel, dim3((unsigned)sr_cdiv(a->N, 256)), dim3(256), 0, (hipStream_t)stream, a->db_partial, a->db,
-                       a->N, a->R > 0 ? a->splits : 0);
+                       a->N, a->R > 0 ? a->splits : 0, a->accumulate);
   return sr_launch_status();
 }
 

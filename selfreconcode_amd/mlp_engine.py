@@ -217,6 +217,26 @@ def interleave(rows):
     return torch.stack(rows, dim=1).reshape(rows[0].shape[0] * len(rows), rows[0].shape[1])
 
 
+import contextlib
+
+_INPUT_GRADS_ONLY = False
+
+
+@contextlib.contextmanager
+def input_grads_only():
+    """Wrap `torch.autograd.grad(outputs, points, ...)` calls that only want d/d(input) (normals, Jacobians):
+    a custom autograd Function cannot see which inputs the engine call targets (`needs_input_grad` is static),
+    so without this hint every such call would also run the weight-gradient GEMMs -- wasted work in plain
+    mode, and WRONG accumulation into the per-step buffers in deferred mode."""
+    global _INPUT_GRADS_ONLY
+    prev = _INPUT_GRADS_ONLY
+    _INPUT_GRADS_ONLY = True
+    try:
+        yield
+    finally:
+        _INPUT_GRADS_ONLY = prev
+
+
 class MLPCoreFunction(torch.autograd.Function):
     """y[P, N_L] = MLP(A0[P, pad4(K0)]; W_l [N_l, pad4(K_l)], b_l)."""
 
@@ -239,7 +259,8 @@ class MLPCoreFunction(torch.autograd.Function):
         saved = ctx.saved_tensors
         nl = len(ctx.spec.layers)
         A0, wb, acts = saved[0], saved[1:1 + 2 * nl], saved[1 + 2 * nl:]
-        outs = MLPCoreBackward.apply(ctx.spec, ctx.needs_input_grad[1], any(ctx.needs_input_grad[2:]), A0, ybar, *wb, *acts)
+        need_par = any(ctx.needs_input_grad[2:]) and not _INPUT_GRADS_ONLY
+        outs = MLPCoreBackward.apply(ctx.spec, ctx.needs_input_grad[1], need_par, A0, ybar, *wb, *acts)
         return (None,) + tuple(outs)
 
 
@@ -258,6 +279,8 @@ class MLPCoreBackward(torch.autograd.Function):
         ctx.spec = spec
         ctx.save_for_backward(A0, ybar, *Ws, *bs)
         ctx.set_materialize_grads(False)
+        if not need_par:
+            dWs, dbs = [None] * nl, [None] * nl
         if A0bar is not None and A0bar.shape[1] != A0.shape[1]:
             A0bar = pad_cols(A0bar[:, :spec.K0], A0.shape[1])
         return (A0bar,) + tuple(dWs) + tuple(dbs)

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .Embedder import embed_rows
-from ..mlp_engine import MLPSpec, mlp_apply, pad_cols, pad4, pack_linear
+from ..mlp_engine import MLPSpec, mlp_apply, pad_cols, pad4, pack_linear, input_grads_only
 from ..utils.utils import resolve_band_weights
 
 
@@ -84,8 +84,9 @@ class ImplicitNetwork(nn.Module):
         if y is None:
             y = self.forward(x)
         d_output = torch.ones_like(y, requires_grad=False, device=y.device)
-        gradients = torch.autograd.grad(outputs=y, inputs=x, grad_outputs=d_output, create_graph=True, retain_graph=True,
-                                        only_inputs=True)[0]
+        with input_grads_only():
+            gradients = torch.autograd.grad(outputs=y, inputs=x, grad_outputs=d_output, create_graph=True, retain_graph=True,
+                                            only_inputs=True)[0]
         return gradients.view(-1, 3)
 
 

@@ -232,7 +232,8 @@ class OptimNetwork(nn.Module):
         device = self.TmpPs.device
         total = 0.
         sdfs = self.sdf(self.TmpPs, ratio)
-        nx = torch.autograd.grad(sdfs, self.TmpPs, torch.ones_like(sdfs), retain_graph=True, create_graph=True)[0]
+        with mlp_engine.input_grads_only():
+            nx = torch.autograd.grad(sdfs, self.TmpPs, torch.ones_like(sdfs), retain_graph=True, create_graph=True)[0]
         nx = nx / nx.norm(dim=1, keepdim=True)
         crays, defVs = U.compute_cardinal_rays(self.deformer, self.TmpPs, self.rays, defconds, self.batch_inds, ratio, 'train')
         if self.conf.get_float('color_weight') > 0.:
@@ -305,7 +306,8 @@ class OptimNetwork(nn.Module):
         v = self.rays.detach()
         p = self.TmpPs
         f = self.sdf(p, ratio)
-        grad_f_p = torch.autograd.grad(f, p, torch.ones_like(f), retain_graph=False)[0]
+        with mlp_engine.input_grads_only():
+            grad_f_p = torch.autograd.grad(f, p, torch.ones_like(f), retain_graph=False)[0]
         d = self.deformer(p, defconds, self.batch_inds, ratio=ratio)
         grad_d_p = U.compute_Jacobian(p, d, False, False).detach()
         opt_defconds = [t for t in (d_cond, poses, trans) if t.requires_grad]

@@ -4,6 +4,7 @@ import torch
 from torch.autograd import Function
 
 from ..ext.FastMinv import Fast3x3Minv, Fast3x3Minv_backward
+from ..mlp_engine import input_grads_only
 
 
 class FastDiff3x3MinvFunction(Function):
@@ -95,7 +96,8 @@ def compute_Jacobian(ps, ds, retain_graph, create_graph, allow_unused=False):
     grad_outputs = torch.ones_like(ds[..., 0])
     for c in range(3):
         rg = True if c < 2 else retain_graph
-        out = torch.autograd.grad(ds[..., c], ps, grad_outputs, retain_graph=rg, create_graph=create_graph, allow_unused=allow_unused)
+        with input_grads_only():
+            out = torch.autograd.grad(ds[..., c], ps, grad_outputs, retain_graph=rg, create_graph=create_graph, allow_unused=allow_unused)
         grad_d_p.append(out[0].view(-1, 1, 3))
     return torch.cat(grad_d_p, dim=1)
 
@@ -104,7 +106,8 @@ def compute_deformed_normals(sdf, deformer, ps, defconds, batch_inds, ratio, pha
     """utils/utils.py:132-153."""
     sdfs = sdf(ps, ratio)
     check = phase in ('train', 'Train')
-    onx = torch.autograd.grad(sdfs, ps, torch.ones_like(sdfs), retain_graph=check, create_graph=check)[0]
+    with input_grads_only():
+        onx = torch.autograd.grad(sdfs, ps, torch.ones_like(sdfs), retain_graph=check, create_graph=check)[0]
     ds = deformer(ps, defconds, batch_inds, ratio=ratio)
     grad_d_p = compute_Jacobian(ps, ds, check, check)
     grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
