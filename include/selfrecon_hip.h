@@ -166,6 +166,15 @@ int sr_lbs_fwd(const sr_lbs_args* host_args, void* stream);
  * transbar [nframes,3] += ybar.  Abar / transbar are accumulated (zero-fill first); each output is nullable. */
 int sr_lbs_bwd(const sr_lbs_args* host_args, const float* ybar, float* pbar, float* Abar, float* transbar, void* stream);
 
+/* SMPL kinematic chain of LBSkinner.forward / posedSkeleton (model/Deformer.py:144-203, smpl_pytorch/util.py:35-78):
+ * poses [B,24,3] axis-angle (device) -> G [B,24,4,4] posed chain and A = G * init_pose [B,24,4,4].
+ * Js [24,3], parents [24] (parents[i] < i), init_pose [24,4,4] are HOST arrays (passed by value to the kernel).
+ * _bwd: posebar [B,24,3] from the cotangents Abar and/or Gbar (nullable). */
+int sr_lbs_chain_fwd(const float* poses, int32_t B, const float* host_Js, const int32_t* host_parents, const float* host_init_pose,
+                     float* G, float* A, void* stream);
+int sr_lbs_chain_bwd(const float* poses, int32_t B, const float* host_Js, const int32_t* host_parents, const float* host_init_pose,
+                     const float* Abar, const float* Gbar, float* posebar, void* stream);
+
 /* ---------------------------------------------------------------- ray/surface refiner step (a12)
  * One iteration body of utils/FindSurfacePs.py::OptimizeSurfacePs (:115-126 check, :135-151 step)
  * for M live rays.  sdf4: output rows of the sdf-only SDF MLP, `group` rows per ray (row 0 = f,

@@ -71,6 +71,8 @@ SIGNATURES = {
     "sr_mlp_gemm_tn_workspace_floats": [ctypes.c_int32, ctypes.c_int32, _i64, _vp],
     "sr_mlp_gemm_tn": [_vp, _vp],
     "sr_colsum_rows": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
+    "sr_lbs_chain_fwd": [_vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sr_lbs_chain_bwd": [_vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sr_lbs_fwd": [_vp, _vp],
     "sr_lbs_bwd": [_vp, _vp, _vp, _vp, _vp, _vp],
     "sr_newton_update": [_vp, _vp],

@@ -227,3 +227,198 @@ extern "C" int sr_lbs_bwd(const sr_lbs_args* a, const float* ybar, float* pbar, 
   hipLaunchKernelGGL(lbs_bwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, *a, ybar, pbar, Abar, transbar);
   return sr_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// SMPL kinematic chain (model/Deformer.py:175-203 / posedSkeleton :144-165): axis-angle -> rotation
+// (half-angle quaternion, +1e-8 inside the norm, smpl_pytorch/util.py:35-78), G_i = G_parent [R_i | J_i - J_parent],
+// A_i = G_i * init_pose_i.  The reference (and a straight torch restatement) issues ~80 tiny launches per call and
+// ~160 more in backward; it is called ~8 times per iteration.  Here: one launch forward, one backward, one thread
+// per frame.  The rotation derivative comes from forward-mode dual numbers (value + 3 partials), so the backward
+// follows the exact same arithmetic as the forward.
+namespace {
+struct Dual {
+  float v, d[3];
+};
+__device__ __forceinline__ Dual mk(float v) { return Dual{v, {0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return Dual{a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2]}}; }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return Dual{a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2]}}; }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) {
+  return Dual{a.v * b.v, {a.d[0] * b.v + a.v * b.d[0], a.d[1] * b.v + a.v * b.d[1], a.d[2] * b.v + a.v * b.d[2]}};
+}
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) {
+  const float iv = 1.f / b.v, q = a.v * iv;
+  return Dual{q, {(a.d[0] - q * b.d[0]) * iv, (a.d[1] - q * b.d[1]) * iv, (a.d[2] - q * b.d[2]) * iv}};
+}
+__device__ __forceinline__ Dual dsqrt(Dual a) { const float s = sqrtf(a.v), h = 0.5f / s; return Dual{s, {a.d[0] * h, a.d[1] * h, a.d[2] * h}}; }
+__device__ __forceinline__ Dual dsin(Dual a) { const float s = sinf(a.v), c = cosf(a.v); return Dual{s, {a.d[0] * c, a.d[1] * c, a.d[2] * c}}; }
+__device__ __forceinline__ Dual dcos(Dual a) { const float s = sinf(a.v), c = cosf(a.v); return Dual{c, {-a.d[0] * s, -a.d[1] * s, -a.d[2] * s}}; }
+
+template <typename S>
+struct Ops;
+template <>
+struct Ops<float> {
+  static __device__ __forceinline__ float c(float v) { return v; }
+  static __device__ __forceinline__ float sq(float a) { return sqrtf(a); }
+  static __device__ __forceinline__ float sn(float a) { return sinf(a); }
+  static __device__ __forceinline__ float cs(float a) { return cosf(a); }
+};
+template <>
+struct Ops<Dual> {
+  static __device__ __forceinline__ Dual c(float v) { return mk(v); }
+  static __device__ __forceinline__ Dual sq(Dual a) { return dsqrt(a); }
+  static __device__ __forceinline__ Dual sn(Dual a) { return dsin(a); }
+  static __device__ __forceinline__ Dual cs(Dual a) { return dcos(a); }
+};
+
+template <typename S>
+__device__ __forceinline__ void rodrigues(S tx, S ty, S tz, S (&R)[9]) {
+  using O = Ops<S>;
+  const S e = O::c(1e-8f);
+  const S ax = tx + e, ay = ty + e, az = tz + e;
+  const S angle = O::sq(ax * ax + ay * ay + az * az);
+  const S nx = tx / angle, ny = ty / angle, nz = tz / angle;
+  const S half = angle * O::c(0.5f);
+  const S qw0 = O::cs(half), sh = O::sn(half);
+  const S qx0 = sh * nx, qy0 = sh * ny, qz0 = sh * nz;
+  const S qn = O::sq(qw0 * qw0 + qx0 * qx0 + qy0 * qy0 + qz0 * qz0);
+  const S w = qw0 / qn, x = qx0 / qn, y = qy0 / qn, z = qz0 / qn;
+  const S w2 = w * w, x2 = x * x, y2 = y * y, z2 = z * z;
+  const S wx = w * x, wy = w * y, wz = w * z, xy = x * y, xz = x * z, yz = y * z;
+  const S two = O::c(2.f);
+  R[0] = w2 + x2 - y2 - z2; R[1] = two * xy - two * wz; R[2] = two * wy + two * xz;
+  R[3] = two * wz + two * xy; R[4] = w2 - x2 + y2 - z2; R[5] = two * yz - two * wx;
+  R[6] = two * xz - two * wy; R[7] = two * wx + two * yz; R[8] = w2 - x2 - y2 + z2;
+}
+
+struct ChainConst {
+  float rel[24 * 3];      // J_i - J_parent (J_0 for the root)
+  float P[24 * 12];       // init_pose (inverse rest chain), rows 0..2 of each 4x4
+  int parent[24];
+};
+
+// G (3x4 per joint, row-major [R|t]) for one frame into g[24*12]
+__device__ __forceinline__ void chain_forward(const float* __restrict__ pose, const ChainConst& cc, float* g) {
+  for (int i = 0; i < 24; ++i) {
+    float R[9];
+    rodrigues<float>(pose[i * 3], pose[i * 3 + 1], pose[i * 3 + 2], R);
+    const float* rel = cc.rel + i * 3;
+    float* gi = g + i * 12;
+    if (i == 0) {
+      for (int r = 0; r < 3; ++r) { gi[r * 4] = R[r * 3]; gi[r * 4 + 1] = R[r * 3 + 1]; gi[r * 4 + 2] = R[r * 3 + 2]; gi[r * 4 + 3] = rel[r]; }
+    } else {
+      const float* gp = g + cc.parent[i] * 12;
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) gi[r * 4 + c] = gp[r * 4] * R[c] + gp[r * 4 + 1] * R[3 + c] + gp[r * 4 + 2] * R[6 + c];
+        gi[r * 4 + 3] = gp[r * 4] * rel[0] + gp[r * 4 + 1] * rel[1] + gp[r * 4 + 2] * rel[2] + gp[r * 4 + 3];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void chain_fwd_kernel(const float* __restrict__ poses, int B, ChainConst cc, float* __restrict__ G,
+                                                        float* __restrict__ A) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float g[24 * 12];
+  chain_forward(poses + (int64_t)b * 72, cc, g);
+  for (int i = 0; i < 24; ++i) {
+    const float* gi = g + i * 12;
+    const float* p = cc.P + i * 12;
+    float* go = G + ((int64_t)b * 24 + i) * 16;
+    float* ao = A + ((int64_t)b * 24 + i) * 16;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 4; ++c) {
+        go[r * 4 + c] = gi[r * 4 + c];
+        ao[r * 4 + c] = gi[r * 4] * p[c] + gi[r * 4 + 1] * p[4 + c] + gi[r * 4 + 2] * p[8 + c] + (c == 3 ? gi[r * 4 + 3] : 0.f);
+      }
+    }
+    go[12] = go[13] = go[14] = 0.f; go[15] = 1.f;
+    ao[12] = ao[13] = ao[14] = 0.f; ao[15] = 1.f;
+  }
+}
+
+// posebar[b,i,:] from the cotangents Abar, Gbar ([B,24,4,4], either nullable)
+__global__ __launch_bounds__(64) void chain_bwd_kernel(const float* __restrict__ poses, int B, ChainConst cc, const float* __restrict__ Abar,
+                                                        const float* __restrict__ Gbar, float* __restrict__ posebar) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float g[24 * 12], gb[24 * 12];
+  const float* pose = poses + (int64_t)b * 72;
+  chain_forward(pose, cc, g);
+  for (int i = 0; i < 24; ++i) {
+    const float* p = cc.P + i * 12;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) {
+        float s = Gbar ? Gbar[((int64_t)b * 24 + i) * 16 + r * 4 + c] : 0.f;
+        if (Abar) {
+          const float* ab = Abar + ((int64_t)b * 24 + i) * 16 + r * 4;
+          // A[r][k] = sum_c G[r][c] P[c][k]  (+ G[r][3] for k == 3): Gbar[r][c] += sum_k Abar[r][k] P[c][k]
+          if (c < 3) s += ab[0] * p[c * 4] + ab[1] * p[c * 4 + 1] + ab[2] * p[c * 4 + 2] + ab[3] * p[c * 4 + 3];
+          else s += ab[3];
+        }
+        gb[i * 12 + r * 4 + c] = s;
+      }
+  }
+  for (int i = 23; i >= 0; --i) {
+    const float* gbi = gb + i * 12;
+    float Rb[9];
+    if (i == 0) {
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rb[r * 3 + c] = gbi[r * 4 + c];
+    } else {
+      const int pa = cc.parent[i];
+      const float* gp = g + pa * 12;
+      float* gbp = gb + pa * 12;
+      float R[9];
+      rodrigues<float>(pose[i * 3], pose[i * 3 + 1], pose[i * 3 + 2], R);
+      const float* rel = cc.rel + i * 3;
+      // G_i = G_p L_i: Gbar_p += Gbar_i L_i^T (L = [R | rel; 0 1]);  Rbar = G_p[:, :3]^T Gbar_i[:, :3]
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+          gbp[r * 4 + c] += gbi[r * 4] * R[c * 3] + gbi[r * 4 + 1] * R[c * 3 + 1] + gbi[r * 4 + 2] * R[c * 3 + 2] + gbi[r * 4 + 3] * rel[c];
+        gbp[r * 4 + 3] += gbi[r * 4 + 3];
+      }
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Rb[r * 3 + c] = gp[0 * 4 + r] * gbi[0 * 4 + c] + gp[1 * 4 + r] * gbi[1 * 4 + c] + gp[2 * 4 + r] * gbi[2 * 4 + c];
+    }
+    Dual R[9];
+    Dual tx{pose[i * 3], {1.f, 0.f, 0.f}}, ty{pose[i * 3 + 1], {0.f, 1.f, 0.f}}, tz{pose[i * 3 + 2], {0.f, 0.f, 1.f}};
+    rodrigues<Dual>(tx, ty, tz, R);
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    for (int e = 0; e < 9; ++e) { o0 += Rb[e] * R[e].d[0]; o1 += Rb[e] * R[e].d[1]; o2 += Rb[e] * R[e].d[2]; }
+    posebar[(int64_t)b * 72 + i * 3] = o0; posebar[(int64_t)b * 72 + i * 3 + 1] = o1; posebar[(int64_t)b * 72 + i * 3 + 2] = o2;
+  }
+}
+
+int fill_chain_const(const float* host_Js, const int32_t* host_parents, const float* host_init_pose, ChainConst& cc) {
+  for (int i = 0; i < 24; ++i) {
+    const int pa = host_parents[i];
+    if (i > 0 && (pa < 0 || pa >= i)) return SR_EINVAL;
+    cc.parent[i] = pa;
+    for (int c = 0; c < 3; ++c) cc.rel[i * 3 + c] = host_Js[i * 3 + c] - (i > 0 ? host_Js[pa * 3 + c] : 0.f);
+    for (int e = 0; e < 12; ++e) cc.P[i * 12 + e] = host_init_pose[i * 16 + e];
+  }
+  return SR_OK;
+}
+}  // namespace
+
+extern "C" int sr_lbs_chain_fwd(const float* poses, int32_t B, const float* host_Js, const int32_t* host_parents,
+                                const float* host_init_pose, float* G, float* A, void* stream) {
+  if (B < 0 || !host_Js || !host_parents || !host_init_pose) return SR_EINVAL;
+  if (B == 0) return SR_OK;
+  if (!poses || !G || !A) return SR_EINVAL;
+  ChainConst cc;
+  if (fill_chain_const(host_Js, host_parents, host_init_pose, cc) != SR_OK) return SR_EINVAL;
+  hipLaunchKernelGGL(chain_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, poses, B, cc, G, A);
+  return sr_launch_status();
+}
+
+extern "C" int sr_lbs_chain_bwd(const float* poses, int32_t B, const float* host_Js, const int32_t* host_parents,
+                                const float* host_init_pose, const float* Abar, const float* Gbar, float* posebar, void* stream) {
+  if (B < 0 || !host_Js || !host_parents || !host_init_pose) return SR_EINVAL;
+  if (B == 0) return SR_OK;
+  if (!poses || !posebar || (!Abar && !Gbar)) return SR_EINVAL;
+  ChainConst cc;
+  if (fill_chain_const(host_Js, host_parents, host_init_pose, cc) != SR_OK) return SR_EINVAL;
+  hipLaunchKernelGGL(chain_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, poses, B, cc, Abar, Gbar, posebar);
+  return sr_launch_status();
+}

@@ -180,13 +180,28 @@ class LBSkinner(nn.Module):
                 G[i] = prod[:, n]
         return torch.stack(G, 1)
 
+    def _host_consts(self):
+        if not hasattr(self, "_hc"):
+            js = (ctypes.c_float * 72)(*self.Js.detach().cpu().view(-1).tolist())
+            pa = (ctypes.c_int32 * 24)(*[max(p, 0) if i else 0 for i, p in enumerate(self.parents)])
+            ip = (ctypes.c_float * 384)(*self.init_pose.detach().cpu().view(-1).tolist())
+            self._hc = (js, pa, ip)
+        return self._hc
+
+    def posed_chain(self, poses):
+        """(G, A): posed kinematic chain and A = G @ init_pose, one fused launch each way (first-order autograd)."""
+        if poses.is_cuda:
+            return _PosedChain.apply(self, poses)
+        G = self._chain(poses)
+        return G, G @ self.init_pose.view(1, 24, 4, 4)
+
     def posed_transforms(self, poses):
-        return self._chain(poses) @ self.init_pose.view(1, 24, 4, 4)
+        return self.posed_chain(poses)[1]
 
     def posedSkeleton(self, conds):
         poses, trans = conds
         assert poses.shape[0] == trans.shape[0]
-        return self._chain(poses)[:, :, :3, 3]
+        return self.posed_chain(poses)[0][:, :, :3, 3]
 
     def fused(self, ps, A, trans, batch_inds=None, with_jac=False, tps=None):
         """No-autograd fused kernel: y (and dy/dp) for flat points [P,3] (batch_inds) or [N,V,3]."""
@@ -268,6 +283,33 @@ class LBSkinner(nn.Module):
         with torch.cuda.device(flat.device):
             _lib.call("sr_lbs_bwd", ctypes.byref(a), _lib.ptr(yb), _lib.ptr(pbar), _lib.ptr(Abar), _lib.ptr(tbar), _lib.stream_of(flat))
         return pbar, Abar, tbar
+
+
+class _PosedChain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, skin, poses):
+        p = poses.detach().contiguous().float().view(-1, 24, 3)
+        B = p.shape[0]
+        G = torch.empty((B, 24, 4, 4), dtype=torch.float32, device=p.device)
+        A = torch.empty_like(G)
+        js, pa, ip = skin._host_consts()
+        with torch.cuda.device(p.device):
+            _lib.call("sr_lbs_chain_fwd", _lib.ptr(p), B, js, pa, ip, _lib.ptr(G), _lib.ptr(A), _lib.stream_of(p))
+        ctx.skin = skin
+        ctx.save_for_backward(p)
+        ctx.pshape = poses.shape
+        return G, A
+
+    @staticmethod
+    def backward(ctx, Gbar, Abar):
+        (p,) = ctx.saved_tensors
+        js, pa, ip = ctx.skin._host_consts()
+        out = torch.empty_like(p)
+        gb = None if Gbar is None else Gbar.contiguous().float()
+        ab = None if Abar is None else Abar.contiguous().float()
+        with torch.cuda.device(p.device):
+            _lib.call("sr_lbs_chain_bwd", _lib.ptr(p), p.shape[0], js, pa, ip, _lib.ptr(ab), _lib.ptr(gb), _lib.ptr(out), _lib.stream_of(p))
+        return None, out.view(ctx.pshape)
 
 
 class _FusedLBS(torch.autograd.Function):

@@ -145,3 +145,20 @@ def test_translator_forward_mode_jacobian_and_its_reverse():
     d2o, _ = orc.translator_forward(sdo, p2, conds, bi, RATIO)
     d2, J2 = translator_value_jacobian(tr, p2.to(DEV), conds.to(DEV), bi.to(DEV), RATIO)
     close(d2, d2o, atol=2e-6)
+
+
+def test_kinematic_chain_kernel_vs_oracle():
+    """fused chain forward/backward (dual-number Rodrigues) == oracle lbs_transforms + autograd."""
+    skin = _skinner()
+    poses = fx.det_tensor((5, 24, 3), 31, 0.4)
+    poses[0, 3] = 0.0                                             # zero rotation: the +1e-8 path
+    po = poses.clone().requires_grad_(True)
+    init_pose = skin.init_pose.cpu()
+    Ao, newJ = orc.lbs_transforms(po, fx.synthetic_joints(), init_pose)
+    ca, cj = fx.det_tensor((5, 24, 4, 4), 32, 1.0), fx.det_tensor((5, 24, 3), 33, 1.0)
+    ref = torch.autograd.grad((Ao * ca).sum() + (newJ * cj).sum(), po)[0]
+    pg = poses.to(DEV).requires_grad_(True)
+    G, A = skin.posed_chain(pg)
+    close(A, Ao, atol=2e-6); close(G[:, :, :3, 3], newJ, atol=2e-6)
+    ours = torch.autograd.grad((A * ca.to(DEV)).sum() + (G[:, :, :3, 3] * cj.to(DEV)).sum(), pg)[0]
+    close(ours, ref, 2e-4, 2e-5)

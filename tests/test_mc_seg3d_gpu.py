@@ -86,8 +86,8 @@ def test_discretize_sdf_mlp_extracts_a_closed_surface():
     def q(points):
         with torch.no_grad():
             return net(points.reshape(-1, 3), 1.0).reshape(1, 1, -1)
-    res = [(9, 13, 5), (17, 25, 9), (33, 49, 17), (65, 97, 33)]
-    eng = Seg3dLossless(q, fx.LBS_BMIN, fx.LBS_BMAX, res, balance_value=0.0).to(DEV)
+    res = [(9, 9, 9), (17, 17, 17), (33, 33, 33), (65, 65, 65)]
+    eng = Seg3dLossless(q, [-0.8, -0.8, -0.8], [0.8, 0.8, 0.8], res, balance_value=0.0).to(DEV)   # box contains the whole sphere
     vol = eng.forward()
     W, H, D = res[-1]
     zs, ys, xs = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(W), indexing='ij')
