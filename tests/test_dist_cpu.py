@@ -1,0 +1,67 @@
+"""world_size-2 gloo tests (CPU) of the frame-parallel data-parallel path: frame sharding, the single flat
+gradient all-reduce (incl. parameters that received no gradient on a rank and the dense per-frame tensors),
+and the template-vertex gradient all-reduce.  The HIP kernels are not involved -- this checks the collective
+logic bench.py runs over RCCL."""
+import os
+import socket
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from selfreconcode_amd import dist as srdist
+    r, w, dev = srdist.init_from_env("cpu")
+    assert (r, w) == (rank, world) and srdist.is_distributed()
+    torch.manual_seed(0)                                   # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1))
+    unused = torch.nn.Parameter(torch.ones(3))             # receives no gradient anywhere (like rcond)
+    frames = torch.arange(8)
+    per_frame = torch.nn.Parameter(torch.zeros(8, 4))      # dense per-frame learnable (poses / codes)
+    data = torch.randn(8, 5, 6, generator=torch.Generator().manual_seed(1))
+    mine = srdist.shard_frames(frames, rank, world)
+    assert mine.tolist() == list(range(rank, 8, world))
+    loss = sum((net(data[f]) ** 2).mean() + (per_frame[f] - f).pow(2).sum() * 0.1 for f in mine) / len(mine)
+    loss.backward()
+    params = list(net.parameters()) + [unused, per_frame]
+    bucket = srdist.GradBucket(params)
+    bucket.all_reduce_mean()
+    tv = torch.full((5, 3), float(rank + 1))
+    srdist.all_reduce_mean_(tv)
+    out.put((rank, [p.grad.clone() for p in params], tv))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_matches_full_batch():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # reference: single process, full batch, mean of the per-rank means
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1))
+    per_frame = torch.nn.Parameter(torch.zeros(8, 4))
+    data = torch.randn(8, 5, 6, generator=torch.Generator().manual_seed(1))
+    loss = 0
+    for r in range(world):
+        mine = list(range(r, 8, world))
+        loss = loss + sum((net(data[f]) ** 2).mean() + (per_frame[f] - f).pow(2).sum() * 0.1 for f in mine) / len(mine) / world
+    loss.backward()
+    ref = [p.grad for p in net.parameters()] + [torch.zeros(3), per_frame.grad]
+    for rank, grads, tv in res:
+        for a, b in zip(grads, ref):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(tv, torch.full((5, 3), 1.5))
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)                           # bit-identical on both ranks -> replicas stay in lock-step
