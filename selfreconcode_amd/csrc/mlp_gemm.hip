@@ -93,7 +93,8 @@ __device__ __forceinline__ void store_tile(float* __restrict__ lds, const f32x4 
 // G rows form one sample (primal + G-1 tangents); all per-sample maths is in-register.
 template <int WM, int WN, int TM, int TN, int G>
 __device__ __forceinline__ void epilogue(const sr_gemm_args& g, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
-                                         int li, int kh) {
+                                         int li, int kh, float* __restrict__ stage) {
+  constexpr int SP = TN * 32 + 4;      // pitch of the per-wave staging image in LDS
   const int ncols = g.N + g.naux_fwd;  // columns of C this launch produces
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
@@ -154,10 +155,33 @@ __device__ __forceinline__ void epilogue(const sr_gemm_args& g, f32x16 (&acc)[TM
             }
           }
         }
+        // results go to the wave's LDS image; rows leave as 16-byte stores below (the MFMA layout would give
+        // 64 dword stores per lane -- store-issue bound, and 2-3x slower on the K=39/K=167 first layers)
+        float* sp = stage + (a * 32 + 8 * q + 4 * kh) * SP + b * 32 + li;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (r0 + j < g.M) g.C[(int64_t)(r0 + j) * g.ldc + col] = o[j];
+        for (int j = 0; j < 4; ++j) sp[j * SP] = o[j];
       }
+    }
+  }
+  __syncthreads();
+  constexpr int QPR = TN * 8;          // float4 per row of the wave tile
+  constexpr int RPI = 64 / QPR;        // rows covered by one wave-wide store
+  const int lane = kh * 32 + li;
+  const int qc = lane % QPR, ro = lane / QPR;
+  const int col0 = n0 + wn * TN * 32 + qc * 4;
+#pragma unroll
+  for (int i = 0; i < TM * 32 / RPI; ++i) {
+    const int lr = i * RPI + ro;
+    const int row = m0 + wm * TM * 32 + lr;
+    if (row >= g.M || col0 >= ncols) continue;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + lr * SP + qc * 4);
+    float* dst = g.C + (int64_t)row * g.ldc + col0;
+    if (col0 + 3 < ncols) {
+      *reinterpret_cast<f32x4*>(dst) = v;
+    } else {
+      dst[0] = v.x;
+      if (col0 + 1 < ncols) dst[1] = v.y;
+      if (col0 + 2 < ncols) dst[2] = v.z;
     }
   }
 }
@@ -234,10 +258,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(sr_gemm_args g) {
   }
 
   // ---------------------------------------------------------------- epilogue
+  float* stage = smem + wave * (TM * 32 * (TN * 32 + 4));   // the operand buffers are free after the last barrier
   switch (g.group) {
-    case 1: epilogue<WM, WN, TM, TN, 1>(g, acc, m0, n0, wm, wn, li, kh); break;
-    case 2: epilogue<WM, WN, TM, TN, 2>(g, acc, m0, n0, wm, wn, li, kh); break;
-    default: epilogue<WM, WN, TM, TN, 4>(g, acc, m0, n0, wm, wn, li, kh); break;
+    case 1: epilogue<WM, WN, TM, TN, 1>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
+    case 2: epilogue<WM, WN, TM, TN, 2>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
+    default: epilogue<WM, WN, TM, TN, 4>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
   }
 }
 
@@ -408,7 +433,7 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
   if (a->M == 0) return SR_OK;
   if (!a->A || !a->B || !a->C) return SR_EINVAL;
   if (a->group != 1 && a->group != 2 && a->group != 4) return SR_EINVAL;
-  if ((a->lda & 3) || (a->ldb & 3) || ((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15)) return SR_EINVAL;
+  if ((a->lda & 3) || (a->ldb & 3) || (a->ldc & 3) || ((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15) || ((uintptr_t)a->C & 15)) return SR_EINVAL;
   if (a->mode != SR_EPI_FWD && a->mode != SR_EPI_BWD) return SR_EINVAL;
   if ((a->naux_fwd > 0 || a->mode == SR_EPI_BWD) && a->act != SR_ACT_NONE && !a->aux && a->mode == SR_EPI_BWD) return SR_EINVAL;
   if (a->mode == SR_EPI_FWD && a->naux_fwd > 0 && !a->aux) return SR_EINVAL;
