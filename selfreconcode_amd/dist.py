@@ -14,6 +14,8 @@ def init_from_env(device_type="cuda"):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if device_type == "cuda":
+        if os.environ.get("SR_ALL_RANKS_ON_DEVICE0") == "1":      # functional test of the N>1 path on a 1-GPU box
+            local = 0
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
     else:
@@ -21,7 +23,8 @@ def init_from_env(device_type="cuda"):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group(backend="nccl" if device_type == "cuda" else "gloo", rank=rank, world_size=world)
+        backend = os.environ.get("SR_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, device
 
 
