@@ -303,7 +303,15 @@ class OptimNetwork(nn.Module):
         poses, trans, d_cond, _ = self.dataset.get_grad_parameters(frame_ids, device)
         defconds = [d_cond, [poses, trans]]
         grad_l_p = self.TmpPs.grad
-        v = self.rays.detach()
+        # rays / camera centre: rebuilt from the (possibly learnable) camera parameters, network.py:715-719
+        cameras, H, W = self._cameras(frame_ids.numel(), device)
+        if self.rays.requires_grad:
+            pixels = torch.stack([self.col_inds, self.row_inds, torch.ones_like(self.col_inds)], dim=-1).float()
+            v_live = cameras.view_rays(pixels)
+        else:
+            v_live = self.rays
+        c_live = cameras.cam_pos()
+        v = v_live.detach()
         p = self.TmpPs
         f = self.sdf(p, ratio)
         with mlp_engine.input_grads_only():
@@ -323,5 +331,11 @@ class OptimNetwork(nn.Module):
         f2 = self.sdf(p.detach(), ratio)
         d2 = self.deformer(p.detach(), defconds, self.batch_inds, ratio=ratio)
         temp = (rhs_1[:, :, -3:].matmul(-v_cross)).view(-1, 3)
-        torch.autograd.backward([f2, d2], [(-rhs_1[:, :, 0]).reshape(f2.shape).detach(), temp.detach()])
+        outs, cots = [f2, d2], [(-rhs_1[:, :, 0]).reshape(f2.shape).detach(), temp.detach()]
+        if v_live.requires_grad:                      # d/dv of [v]x (d - c): network.py:798-809
+            dc_cross = cross_matrix(d2.detach() - c_live.detach().view(1, 3))
+            outs.append(v_live); cots.append(rhs_1[:, :, -3:].matmul(dc_cross).view(-1, 3).detach())
+        if c_live.requires_grad:                      # network.py:811-813
+            outs.append(c_live); cots.append((-temp.sum(0)).detach())
+        torch.autograd.backward(outs, cots)
         mlp_engine.flush_param_grads()       # last gradient producer of the step (no-op unless deferred mode is on)
