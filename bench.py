@@ -124,6 +124,12 @@ def main():
                      "launches": prof["launches"], "avg_launch_us": prof["avg_us"], "flop_per_launch": prof["avg_flop"],
                      "traffic": None},
     }
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_nt.json")      # PMC passes cannot run inside this process; latest committed collection
+    if os.path.isfile(pmc):
+        with open(pmc) as fh:
+            t = json.load(fh)
+        out["roofline"]["traffic"] = round(t["traffic_bytes_per_launch"])
+        out["roofline"]["traffic_note"] = "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01_pmc_gemm_nt.json)"
     if world == 1 and not args.no_cpu_baseline:
         from oracle.cpu_baseline import estimate_iteration_seconds       # checker-side code, baseline leg only
         sec, parts, threads = estimate_iteration_seconds(V, rays_total / max(len(conv), 1), FRAMES_PER_RANK,
