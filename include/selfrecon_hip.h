@@ -224,6 +224,16 @@ int sr_splat_fwd(const float* pix, const uint8_t* vis, int64_t nimg, int64_t pts
 int sr_splat_bwd(const float* pix, const uint8_t* vis, int64_t nimg, int64_t pts_per_img, int32_t H, int32_t W, float radius_px,
                  const float* logT, const float* gmask, float* gpix, void* stream);
 
+/* ---------------------------------------------------------------- interp2x_boundary3d (K10/K11)
+ * Replaces MCAcc/cuda/interp2x_boundary3d.cpp:forward/backward -> interp2x_boundary3d_kernel.cu:11-151, 155-239
+ * (compiled but never enabled in the reference: every Seg3dLossless is built with use_cuda_impl=False).
+ * in [BC, d,h,w] -> out [BC, 2d-1,2h-1,2w-1] = mean of the 1/2/4/8 coarse parents; is_boundary (u8) = parents'
+ * (v > balance) flags disagree.  _bwd: grad_out [BC, 2d-1,2h-1,2w-1] -> grad_in [BC, d,h,w] (adjoint stencil). */
+int sr_interp2x3d_fwd_f32(const float* in, int64_t BC, int32_t d, int32_t h, int32_t w, float balance, float* out, uint8_t* is_boundary, void* stream);
+int sr_interp2x3d_fwd_f64(const double* in, int64_t BC, int32_t d, int32_t h, int32_t w, float balance, double* out, uint8_t* is_boundary, void* stream);
+int sr_interp2x3d_bwd_f32(const float* grad_out, int64_t BC, int32_t d, int32_t h, int32_t w, float* grad_in, void* stream);
+int sr_interp2x3d_bwd_f64(const double* grad_out, int64_t BC, int32_t d, int32_t h, int32_t w, double* grad_in, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,7 +46,8 @@ class Seg3dLossless(nn.Module):
         self.by = self.b_min.view(-1)[1].item() + self.spacing_y / 2.
         self.bz = self.b_min.view(-1)[2].item() + self.spacing_z / 2.
         assert self.b_min.size(0) == 1 and channels == 1 and align_corners is False and visualize is False
-        assert not use_cuda_impl and not faster and not use_shadow, "only the mode the reference uses is built"
+        assert not faster and not use_shadow, "faster / shadow modes of the reference are not built (never used by it)"
+        self.use_cuda_impl = use_cuda_impl          # fused HIP upsample + boundary flag (the reference ships it switched off)
         self.balance_value = balance_value
         for r in self._res:
             assert r[0] % 2 == 1 and r[1] % 2 == 1, f"resolution {r} need to be odd becuase of align_corner."
@@ -87,9 +88,14 @@ class Seg3dLossless(nn.Module):
             nd = torch.zeros((D, H, W), dtype=torch.bool, device=dev)
             nd[::2, ::2, ::2] = done                                             # evaluated voxels carry over (coords_accum *= 2)
             done = nd
-            valid = F.interpolate((occ > bal).float(), size=(D, H, W), mode="trilinear", align_corners=True)
-            occ = F.interpolate(occ.float(), size=(D, H, W), mode="trilinear", align_corners=True)
-            boundary = ((valid > 0.0) & (valid < 1.0)).float()
+            if self.use_cuda_impl:
+                from ..ext import interp2x_boundary3d
+                occ, bflag = interp2x_boundary3d.forward(occ.float().contiguous(), bal)
+                boundary = bflag.float()
+            else:
+                valid = F.interpolate((occ > bal).float(), size=(D, H, W), mode="trilinear", align_corners=True)
+                occ = F.interpolate(occ.float(), size=(D, H, W), mode="trilinear", align_corners=True)
+                boundary = ((valid > 0.0) & (valid < 1.0)).float()
             boundary = F.max_pool3d(boundary, kernel_size=3, stride=1, padding=1)[0, 0] > 0     # == smooth_conv3x3(.) > 0
             boundary &= ~done
             idx = boundary.view(-1).nonzero(as_tuple=False).view(-1)             # flat index z*H*W + y*W + x

@@ -5,7 +5,8 @@ import sys
 
 
 def install():
-    from .ext import FastMinv, GridSamplerMine, MCGpu
+    from .ext import FastMinv, GridSamplerMine, MCGpu, interp2x_boundary3d
+    sys.modules['interp2x_boundary3d'] = interp2x_boundary3d
     sys.modules['FastMinv'] = FastMinv
     sys.modules['GridSamplerMine'] = GridSamplerMine
     sys.modules['MCGpu'] = MCGpu

@@ -98,3 +98,64 @@ def test_discretize_sdf_mlp_extracts_a_closed_surface():
     verts, faces = MCGpu.mc_gpu(vol[0, 0].permute(2, 1, 0).contiguous(), eng.spacing_x, eng.spacing_y, eng.spacing_z, eng.bx, eng.by, eng.bz, 0.)
     r = verts.norm(dim=1)
     assert faces.min() >= 0 and 0.3 < float(r.min()) and float(r.max()) < 0.9
+
+
+def _interp2x_numpy(a, bal):
+    """restatement of interp2x_boundary3d_kernel.cu:11-151 in numpy (float32 parent sums, division in double)."""
+    d, h, w = a.shape
+    D, H, W = 2 * d - 1, 2 * h - 1, 2 * w - 1
+    out = np.zeros((D, H, W), np.float32); bnd = np.zeros((D, H, W), bool)
+    for z in range(D):
+        for y in range(H):
+            for x in range(W):
+                zs = [z // 2] if z % 2 == 0 else [(z - 1) // 2, (z + 1) // 2]
+                ys = [y // 2] if y % 2 == 0 else [(y - 1) // 2, (y + 1) // 2]
+                xs = [x // 2] if x % 2 == 0 else [(x - 1) // 2, (x + 1) // 2]
+                if len(zs) == 2 and len(ys) == 2 and len(xs) == 2: order = [(zz, yy, xx) for zz in zs for yy in ys for xx in xs]
+                elif len(zs) == 1: order = [(zs[0], yy, xx) for yy in ys for xx in xs]
+                elif len(xs) == 1: order = [(zz, yy, xs[0]) for yy in ys for zz in zs]
+                else: order = [(zz, ys[0], xx) for xx in xs for zz in zs]
+                vals = [a[p] for p in order]
+                s = np.float32(vals[0])
+                for v in vals[1:]:
+                    s = np.float32(s + v)
+                out[z, y, x] = s if len(vals) == 1 else np.float32(np.float64(s) / len(vals))
+                bnd[z, y, x] = len({bool(v > bal) for v in vals}) > 1
+    return out, bnd
+
+
+def test_interp2x_boundary3d_forward_backward():
+    from selfreconcode_amd.MCAcc.interp2x_boundary3d import Interp2xBoundary3d
+    a = fx.det_array((5, 4, 6), 77, 1.0)
+    ref_o, ref_b = _interp2x_numpy(a, 0.1)
+    x = torch.from_numpy(a).to(DEV).view(1, 1, 5, 4, 6).requires_grad_(True)
+    out, bnd = Interp2xBoundary3d(0.1)(x)
+    assert out.shape == (1, 1, 9, 7, 11) and bnd.dtype == torch.bool
+    assert np.array_equal(out[0, 0].detach().cpu().numpy(), ref_o) and np.array_equal(bnd[0, 0].cpu().numpy(), ref_b)
+    # == F.interpolate(trilinear, align_corners=True) to 1 ulp, boundary == (0 < interp(sign) < 1): what Seg3dLossless uses otherwise
+    ti = torch.nn.functional.interpolate(x.detach(), size=(9, 7, 11), mode="trilinear", align_corners=True)
+    torch.testing.assert_close(out.detach(), ti, rtol=2e-7, atol=1e-7)
+    valid = torch.nn.functional.interpolate((x.detach() > 0.1).float(), size=(9, 7, 11), mode="trilinear", align_corners=True)
+    assert torch.equal(bnd, (valid > 0) & (valid < 1))
+    go = fx.det_tensor((1, 1, 9, 7, 11), 78, 1.0).to(DEV)
+    (g,) = torch.autograd.grad(out, x, go)
+    xr = x.detach().clone().requires_grad_(True)
+    (gr,) = torch.autograd.grad(torch.nn.functional.interpolate(xr, size=(9, 7, 11), mode="trilinear", align_corners=True), xr, go)
+    torch.testing.assert_close(g, gr, rtol=1e-5, atol=1e-6)                  # adjoint stencil == autograd of the interpolation
+    xd = x.detach().double().requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda t: Interp2xBoundary3d(0.1)(t)[0], (xd,))
+
+
+def test_seg3d_with_fused_upsampler_is_still_lossless():
+    from selfreconcode_amd.MCAcc import Seg3dLossless
+
+    def ell(points):
+        c = torch.tensor([0.05, -0.1, 0.02], device=points.device).view(1, 1, 3)
+        a = torch.tensor([0.45, 0.8, 0.25], device=points.device).view(1, 1, 3)
+        return (((points - c) / a).norm(dim=-1) - 1.0).view(1, 1, -1) * 0.25
+    res = [(5, 7, 3), (9, 13, 5), (17, 25, 9), (33, 49, 17)]
+    a = Seg3dLossless(ell, [-0.8, -1.25, -0.4], [0.8, 0.95, 0.4], res, balance_value=0.0, use_cuda_impl=True).to(DEV)
+    b = Seg3dLossless(ell, [-0.8, -1.25, -0.4], [0.8, 0.95, 0.4], res, balance_value=0.0, use_cuda_impl=False).to(DEV)
+    va, vb = a.forward(), b.forward()
+    assert ((va > 0) == (vb > 0)).all() and a.stats["queries"] == b.stats["queries"]
+    torch.testing.assert_close(va, vb, rtol=1e-6, atol=1e-7)
