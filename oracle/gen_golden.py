@@ -244,3 +244,14 @@ vol_out = eng.forward()
 save("seg3d", vol=vol_out[0, 0], nq=np.array(nq[0]), spacing=np.array([eng.spacing_x, eng.spacing_y, eng.spacing_z]),
      origin=np.array([eng.bx, eng.by, eng.bz]))
 print("done")
+
+# ---------------------------------------------------------------- state_dict key/shape contract (checkpoint compatibility, utils/utils.py:257-316)
+import json
+keys = {}
+for name, mod in (("sdf", ref.network.getTmpSdf("cpu", 6, 0.6, 256)), ("translator", ref.Deformer.MLPTranslator(128, 6)),
+                  ("render", ref.RenderNet.RenderingNetwork_view_norm(256, 'idr', 9, 3, [512, 512, 512, 512], True, multires_n=0, multires_v=4)),
+                  ("skinner", skin)):
+    keys[name] = {k: list(v.shape) for k, v in mod.state_dict().items()}
+with open(os.path.join(OUT, "state_keys.json"), "w") as fh:
+    json.dump(keys, fh, indent=0, sort_keys=True)
+print("wrote state_keys.json", {k: len(v) for k, v in keys.items()})

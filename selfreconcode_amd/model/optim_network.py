@@ -63,6 +63,47 @@ class OptimNetwork(nn.Module):
         self.dataset = None
         self.dctnull = None
 
+    # ------------------------------------------------------------------ SDF pre-fit (network.py:207-290)
+    def initializeTmpSDF(self, nepochs, save_name=None, with_normals=False, verbose=False):
+        """Fits the SDF to the body template `self.tmpBodyVs` (+ `self.tmpBodyNs`): |f| on the surface, eikonal term off it,
+        optional normal alignment; Adam lr 0.005, StepLR(500, 0.5), batches of 5000 points -- the reference's schedule."""
+        network = self.sdf
+        network.train()
+        optimizer = torch.optim.Adam([{"params": network.parameters(), "lr": 0.005, "weight_decay": 0}])
+        sche = torch.optim.lr_scheduler.StepLR(optimizer, 500, 0.5)
+        vs = self.tmpBodyVs
+        ns = getattr(self, 'tmpBodyNs', None)
+        with_normals = with_normals and ns is not None
+        if not with_normals:
+            ns = torch.ones_like(vs) / np.sqrt(3)
+        last = None
+        for epoch in range(1, nepochs + 1):
+            perm = torch.randperm(vs.shape[0], device=vs.device)
+            for mnfld_pnts, normals in zip(torch.split(vs[perm], 5000), torch.split(ns[perm], 5000)):
+                nonmnfld_pnts = U.sample_points(mnfld_pnts, 1.8, 0.01)
+                mnfld_pnts = mnfld_pnts.detach().clone().requires_grad_()
+                nonmnfld_pnts.requires_grad_()
+                mnfld_pred = network(mnfld_pnts, -1)
+                nonmnfld_pred = network(nonmnfld_pnts, -1)
+                mnfld_grad = network.gradient(mnfld_pnts, mnfld_pred) if with_normals else None
+                nonmnfld_grad = network.gradient(nonmnfld_pnts, nonmnfld_pred)
+                mnfld_loss = mnfld_pred.abs().mean()
+                grad_loss = ((nonmnfld_grad.norm(2, dim=-1) - 1) ** 2).mean()
+                loss = mnfld_loss + 0.1 * grad_loss
+                if with_normals:
+                    loss = loss + 1.0 * ((mnfld_grad - normals.view(-1, 3)).abs()).norm(2, dim=1).mean()
+                optimizer.zero_grad()
+                loss.backward()
+                mlp_engine.flush_param_grads()
+                optimizer.step()
+                last = (loss.detach(), mnfld_loss.detach(), grad_loss.detach())
+            sche.step()
+            if verbose and last is not None:
+                print('Train Epoch: {}\tTrain Loss: {:.6f}\tManifold loss: {:.6f}\tGrad loss: {:.6f}'.format(epoch, *[float(t) for t in last]))
+        if save_name:
+            torch.save(network.state_dict(), save_name)
+        return last
+
     # ------------------------------------------------------------------ geometry extraction (a16 + a17)
     def discretizeSDF(self, ratio, engine=None, balance_value=0.):
         def query_func(points):
