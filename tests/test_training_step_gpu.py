@@ -227,3 +227,18 @@ def test_camera_parameters_receive_gradients_when_learnable():
         g1 = ds.camera_params[k].grad
         assert torch.isfinite(g1).all() and g1.abs().sum() > 0
     assert not torch.equal(ds.camera_params['world2cam_coord_trans'].grad, g0['world2cam_coord_trans'])   # the c-term added something
+
+
+def test_initialize_tmp_sdf_prefit_reduces_the_manifold_loss():
+    """network.py:207-290: a few epochs of the pre-fit pull |f| on the template surface towards 0."""
+    from selfreconcode_amd.synthetic import build_synthetic_scene
+    net, ds, conf = build_synthetic_scene(device=DEV, frame_num=40, H=64, W=64, resolutions=[(15, 21, 9), (29, 41, 17)], lbs_volume_shape=(9, 29, 17))
+    dirs = torch.nn.functional.normalize(fx.det_tensor((4000, 3), 3, 1.0), dim=1).to(DEV)
+    net.tmpBodyVs = dirs * torch.tensor([0.35, 0.5, 0.25], device=DEV)            # an ellipsoid "body"
+    net.tmpBodyNs = torch.nn.functional.normalize(dirs / torch.tensor([0.35, 0.5, 0.25], device=DEV), dim=1)
+    with torch.no_grad():
+        before = net.sdf(net.tmpBodyVs, -1).abs().mean()
+    last = net.initializeTmpSDF(12, None, with_normals=True)
+    with torch.no_grad():
+        after = net.sdf(net.tmpBodyVs, -1).abs().mean()
+    assert torch.isfinite(last[0]) and float(after) < 0.5 * float(before)
