@@ -234,6 +234,15 @@ int sr_interp2x3d_fwd_f64(const double* in, int64_t BC, int32_t d, int32_t h, in
 int sr_interp2x3d_bwd_f32(const float* grad_out, int64_t BC, int32_t d, int32_t h, int32_t w, float* grad_in, void* stream);
 int sr_interp2x3d_bwd_f64(const double* grad_out, int64_t BC, int32_t d, int32_t h, int32_t w, double* grad_in, void* stream);
 
+/* Hard mesh rasteriser: stands where the reference calls pytorch3d's MeshRasterizer (model/network.py:492;
+ * faces_per_pixel=1, blur 0, perspective-correct barycentrics, no culling) to seed its rays through FindSurfacePs.
+ * pix [nimg,V,2] projected pixel coordinates (x = column, y = row; integer = pixel centre), z [nimg,V] camera depth,
+ * faces [F,3] int64 shared by all images (rows containing -1 are skipped).  Outputs: pix_to_face [nimg,H,W] int64
+ * (packed index img*F + f, -1 = background), bary [nimg,H,W,3] (-1 on background), zout [nimg,H,W] nullable.
+ * zbuf_u64: scratch of nimg*H*W 8-byte words.  Third-party behaviour, parity unpinned (no pytorch3d here). */
+int sr_raster_mesh(const float* pix, const float* z, const int64_t* faces, int64_t nimg, int64_t V, int64_t F, int32_t H, int32_t W,
+                   void* zbuf_u64, int64_t* pix_to_face, float* bary, float* zout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

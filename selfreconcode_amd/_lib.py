@@ -86,6 +86,7 @@ SIGNATURES = {
     "sr_interp2x3d_fwd_f64": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp],
     "sr_interp2x3d_bwd_f32": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
     "sr_interp2x3d_bwd_f64": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
+    "sr_raster_mesh": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp],
     "sr_pe_embed_bwd": [_vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _i64, _vp, _vp],
     "sr_pe_embed": [_vp, _i64, ctypes.c_int32, _vp, _vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _i64, _vp],
 }

@@ -155,3 +155,92 @@ int sr_splat_bwd(const float* pix, const uint8_t* vis, int64_t nimg, int64_t pts
   return sr_launch_status();
 }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Hard mesh rasteriser: nearest triangle per pixel centre + perspective-correct
+// barycentrics -- what the reference takes from pytorch3d's MeshRasterizer(faces_per_pixel=1, blur_radius=0,
+// perspective_correct=True, cull_backfaces=False) at model/network.py:492 to seed its rays (FindSurfacePs).
+// Pass 1: one thread per (image, face): bounding box, inside test at pixel centres, 64-bit atomicMin of
+// (depth bits << 32 | face).  Pass 2: one thread per pixel: barycentrics of the winning face.
+namespace {
+struct Tri { float x0, y0, z0, x1, y1, z1, x2, y2, z2; };
+
+__device__ __forceinline__ bool load_tri(const float* __restrict__ pix, const float* __restrict__ z, const int64_t* __restrict__ faces,
+                                         int64_t img, int64_t V, int64_t f, Tri& t) {
+  const int64_t a = faces[f * 3], b = faces[f * 3 + 1], c = faces[f * 3 + 2];
+  if (a < 0 || b < 0 || c < 0) return false;
+  const int64_t o = img * V;
+  t.x0 = pix[(o + a) * 2]; t.y0 = pix[(o + a) * 2 + 1]; t.z0 = z[o + a];
+  t.x1 = pix[(o + b) * 2]; t.y1 = pix[(o + b) * 2 + 1]; t.z1 = z[o + b];
+  t.x2 = pix[(o + c) * 2]; t.y2 = pix[(o + c) * 2 + 1]; t.z2 = z[o + c];
+  return t.z0 > 0.f && t.z1 > 0.f && t.z2 > 0.f;
+}
+
+// barycentrics of pixel centre (px,py); returns false when outside (or degenerate)
+__device__ __forceinline__ bool bary_of(const Tri& t, float px, float py, float& b0, float& b1, float& b2, float& depth) {
+  const float area = (t.x1 - t.x0) * (t.y2 - t.y0) - (t.x2 - t.x0) * (t.y1 - t.y0);
+  if (fabsf(area) < 1e-12f) return false;
+  const float w0 = ((t.x1 - px) * (t.y2 - py) - (t.x2 - px) * (t.y1 - py)) / area;
+  const float w1 = ((t.x2 - px) * (t.y0 - py) - (t.x0 - px) * (t.y2 - py)) / area;
+  const float w2 = 1.0f - w0 - w1;
+  if (w0 < 0.f || w1 < 0.f || w2 < 0.f) return false;
+  const float i0 = w0 / t.z0, i1 = w1 / t.z1, i2 = w2 / t.z2;     // perspective correction
+  const float s = i0 + i1 + i2;
+  b0 = i0 / s; b1 = i1 / s; b2 = i2 / s;
+  depth = 1.0f / s;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void raster_pass1(const float* __restrict__ pix, const float* __restrict__ z, const int64_t* __restrict__ faces,
+                                                     int64_t nimg, int64_t V, int64_t F, int H, int W, unsigned long long* __restrict__ zbuf) {
+  const int64_t total = nimg * F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t img = i / F, f = i % F;
+    Tri t;
+    if (!load_tri(pix, z, faces, img, V, f, t)) continue;
+    const int xmin = max(0, (int)ceilf(fminf(t.x0, fminf(t.x1, t.x2)))), xmax = min(W - 1, (int)floorf(fmaxf(t.x0, fmaxf(t.x1, t.x2))));
+    const int ymin = max(0, (int)ceilf(fminf(t.y0, fminf(t.y1, t.y2)))), ymax = min(H - 1, (int)floorf(fmaxf(t.y0, fmaxf(t.y1, t.y2))));
+    if (xmax - xmin > 256 || ymax - ymin > 256) continue;     // guard against a degenerate projection covering the image
+    for (int y = ymin; y <= ymax; ++y)
+      for (int x = xmin; x <= xmax; ++x) {
+        float b0, b1, b2, d;
+        if (!bary_of(t, (float)x, (float)y, b0, b1, b2, d)) continue;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned int)f;
+        atomicMin(zbuf + (img * H + y) * W + x, key);
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void raster_pass2(const float* __restrict__ pix, const float* __restrict__ z, const int64_t* __restrict__ faces,
+                                                     int64_t nimg, int64_t V, int64_t F, int H, int W, const unsigned long long* __restrict__ zbuf,
+                                                     int64_t* __restrict__ pix_to_face, float* __restrict__ bary, float* __restrict__ zout) {
+  const int64_t total = nimg * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long key = zbuf[i];
+    int64_t out = -1;
+    float b0 = -1.f, b1 = -1.f, b2 = -1.f, d = -1.f;
+    if (key != 0xFFFFFFFFFFFFFFFFull) {
+      const int64_t img = i / ((int64_t)H * W), f = (int64_t)(key & 0xFFFFFFFFull);
+      const int y = (int)((i / W) % H), x = (int)(i % W);
+      Tri t;
+      if (load_tri(pix, z, faces, img, V, f, t) && bary_of(t, (float)x, (float)y, b0, b1, b2, d)) out = img * F + f;   // packed index, as pytorch3d
+    }
+    pix_to_face[i] = out;
+    bary[i * 3] = b0; bary[i * 3 + 1] = b1; bary[i * 3 + 2] = b2;
+    if (zout) zout[i] = d;
+  }
+}
+}  // namespace
+
+extern "C" int sr_raster_mesh(const float* pix, const float* z, const int64_t* faces, int64_t nimg, int64_t V, int64_t F, int32_t H, int32_t W,
+                              void* zbuf_u64, int64_t* pix_to_face, float* bary, float* zout, void* stream) {
+  if (nimg < 0 || V < 0 || F < 0 || H <= 0 || W <= 0) return SR_EINVAL;
+  if (nimg == 0) return SR_OK;
+  if (!zbuf_u64 || !pix_to_face || !bary || (F > 0 && (!pix || !z || !faces))) return SR_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(zbuf_u64, 0xFF, (size_t)nimg * H * W * 8, st) != hipSuccess) return SR_ELAUNCH;
+  if (F > 0) hipLaunchKernelGGL(raster_pass1, dim3(sr_stream_grid(nimg * F, 256)), dim3(256), 0, st, pix, z, faces, nimg, V, F, H, W, (unsigned long long*)zbuf_u64);
+  hipLaunchKernelGGL(raster_pass2, dim3(sr_stream_grid(nimg * H * W, 256)), dim3(256), 0, st, pix, z, faces, nimg, V, F, H, W,
+                     (const unsigned long long*)zbuf_u64, pix_to_face, bary, zout);
+  return sr_launch_status();
+}

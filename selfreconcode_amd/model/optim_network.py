@@ -22,7 +22,7 @@ from .. import dist as srdist
 from .. import mlp_engine
 from ..ext import MCGpu
 from ..ext.FastMinv import Fast3x3Minv
-from ..ops import singular_values_3x3, splat_silhouette
+from ..ops import singular_values_3x3, splat_silhouette, rasterize_mesh
 from ..utils import utils as U
 from ..utils.FindSurfacePs import FindSurfacePs, OptimizeSurfacePs
 from .CameraMine import RectifiedPerspectiveCameras
@@ -58,6 +58,7 @@ class OptimNetwork(nn.Module):
         self.remesh_time = 0.
         self.point_radius = 0.006             # train.coarse.point_render.radius (config.conf:30)
         self.sdfShrinkRadius = 0.0
+        self.seed_mode = "mesh"               # "mesh": triangle rasteriser + FindSurfacePs; "vertex": vertex z-buffer stand-in
         self.TmpPs = None
         self.info = {}
         self.dataset = None
@@ -175,6 +176,10 @@ class OptimNetwork(nn.Module):
         with torch.no_grad():
             if 'frags' in datas:
                 batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(self.TmpVs.detach(), self.Tmpfs, datas['frags'])
+            elif self.seed_mode == "mesh":            # in-repo hard mesh rasteriser -> FindSurfacePs, as the reference does with pytorch3d
+                pix, z = cameras.project(defTmpVs.detach())
+                frags = rasterize_mesh(pix, z, self.Tmpfs, H, W)
+                batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(self.TmpVs.detach(), self.Tmpfs, frags)
             else:
                 batch_inds, row_inds, col_inds, initTmpPs = self._seed_rays(defTmpVs.detach(), cameras, H, W)
         masks = self._silhouette(defTmpVs, cameras, H, W, self.point_radius)

@@ -59,3 +59,26 @@ class SplatSilhouette(Function):
 
 def splat_silhouette(pix, vis, H, W, radius_px):
     return SplatSilhouette.apply(pix, vis, H, W, radius_px)
+
+
+class Fragments:
+    """pix_to_face [N,H,W,1], bary_coords [N,H,W,1,3], zbuf [N,H,W,1] -- the fields FindSurfacePs reads from pytorch3d's Fragments."""
+
+    def __init__(self, pix_to_face, bary_coords, zbuf):
+        self.pix_to_face, self.bary_coords, self.zbuf = pix_to_face, bary_coords, zbuf
+
+
+def rasterize_mesh(pix, z, faces, H, W):
+    """No-grad hard rasterisation of N images of one mesh topology (see sr_raster_mesh)."""
+    _lib.require_gpu(pix)
+    pix = pix.detach().contiguous().float(); z = z.detach().contiguous().float(); faces = faces.contiguous()
+    N, V = pix.shape[0], pix.shape[1]
+    dev = pix.device
+    zbuf = torch.empty((N, H, W), dtype=torch.int64, device=dev)
+    p2f = torch.empty((N, H, W), dtype=torch.int64, device=dev)
+    bary = torch.empty((N, H, W, 3), dtype=torch.float32, device=dev)
+    zo = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("sr_raster_mesh", _lib.ptr(pix), _lib.ptr(z), _lib.ptr(faces), N, V, faces.shape[0], H, W, _lib.ptr(zbuf), _lib.ptr(p2f),
+                  _lib.ptr(bary), _lib.ptr(zo), _lib.stream_of(pix))
+    return Fragments(p2f.unsqueeze(-1), bary.unsqueeze(3), zo.unsqueeze(-1))
