@@ -442,7 +442,13 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
   const int ncols = a->N + (a->mode == SR_EPI_FWD ? a->naux_fwd : 0);
   sr_gemm_args g = *a;
   if (g.mode != SR_EPI_FWD) g.naux_fwd = 0;
-  if (ncols <= 32) {
+  if (g.M <= 4096 && ncols > 32) {
+    // small batches (converged-ray branches, a few hundred to a few thousand rows): a 128x128 tile leaves >90% of the
+    // CUs idle and still costs a full 16-step K loop (~40 us); 64x64 tiles give 4x the workgroups at 1/4 the latency.
+    using C_ = Cfg<2, 2, 1, 1>;
+    const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));
+    hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 1, 1>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), (hipStream_t)stream, g);
+  } else if (ncols <= 32) {
     using C_ = Cfg<4, 1, 2, 1>;
     const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));
     hipLaunchKernelGGL((gemm_nt_kernel<4, 1, 2, 1>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), (hipStream_t)stream, g);

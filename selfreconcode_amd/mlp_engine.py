@@ -424,7 +424,7 @@ def set_deferred_param_grads(flag):
 
 def _deferred_sink(W, b):
     e = _ENTRY_BY_PTR.get(W.data_ptr())
-    if e is None or b is None or not b.requires_grad:
+    if e is None or b is None or not b.requires_grad or not b.is_leaf or W.shape[0] != e["W"].shape[0]:
         return None
     if e.get("dW") is None:
         e["dW"] = torch.zeros_like(e["W"])

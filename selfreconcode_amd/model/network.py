@@ -57,6 +57,8 @@ class ImplicitNetwork(nn.Module):
                 lin = nn.utils.weight_norm(lin)
             setattr(self, "lin" + str(l), lin)
         self.spec = MLPSpec.sdf(multires, dims[1], self.num_layers - 1, self.skip_in, dims[-1])
+        last = self.spec.layers[-1]
+        self.spec_sdf_only = MLPSpec(self.spec.layers[:-1] + [type(last)(last.K, d_out, last.act)], self.spec.K0)
         self.rendcond = None
 
     def packed_weights(self):
@@ -67,10 +69,15 @@ class ImplicitNetwork(nn.Module):
             bs.append(lin.bias)
         return Ws, bs
 
-    def forward(self, input, ratio=None):
+    def forward(self, input, ratio=None, sdf_only=False):
+        """`sdf_only=True` (extension): evaluate only the d_out distance rows of the last layer -- for callers that never
+        read `rendcond` (mask/eikonal terms, refiner, volume queries): skips 256 of its 257 output rows."""
         ratio = ratio if type(ratio) == float or type(ratio) == int or ratio is None else ratio['sdfRatio']
         A0 = embed_rows(input, self.multires, resolve_band_weights(self.multires, ratio))
         Ws, bs = self.packed_weights()
+        if sdf_only:
+            self.rendcond = None
+            return mlp_apply(self.spec_sdf_only, A0, Ws[:-1] + [Ws[-1][:self.d_out]], bs[:-1] + [bs[-1][:self.d_out]])
         x = mlp_apply(self.spec, A0, Ws, bs)
         if x.shape[-1] > self.d_out:
             self.rendcond = x[:, self.d_out:]

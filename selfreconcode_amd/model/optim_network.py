@@ -109,7 +109,7 @@ class OptimNetwork(nn.Module):
     def discretizeSDF(self, ratio, engine=None, balance_value=0.):
         def query_func(points):
             with torch.no_grad():
-                return self.sdf.forward(points.reshape(-1, 3), ratio).reshape(1, 1, -1)
+                return self.sdf.forward(points.reshape(-1, 3), ratio, sdf_only=True).reshape(1, 1, -1)
         if engine is None:
             engine = self.engine
         engine.balance_value = balance_value
@@ -254,7 +254,7 @@ class OptimNetwork(nn.Module):
             noise_global = torch.rand(n_global, 3, device=base.device)
         pts = torch.cat([base + noise_local * 0.01, noise_global * (1.8 * 2) - 1.8], dim=0)
         pts.requires_grad_()
-        pred = self.sdf(pts, ratio)
+        pred = self.sdf(pts, ratio, sdf_only=True)
         grad = self.sdf.gradient(pts, pred)
         return ((grad.norm(2, dim=-1) - 1) ** 2).mean()
 
@@ -332,7 +332,7 @@ class OptimNetwork(nn.Module):
         mlp_engine.flush_param_grads()       # last gradient producer of the step (no-op unless deferred mode is on)
         srdist.all_reduce_mean_(self.TmpVs.grad)     # shared template: exact batch semantics across ranks
         self.TmpOptimizer.step()
-        mnfld_pred = self.sdf(self.TmpVs, ratio).view(-1)
+        mnfld_pred = self.sdf(self.TmpVs, ratio, sdf_only=True).view(-1)
         sdf_loss = (mnfld_pred + self.sdfShrinkRadius).abs().mean()
         self.info['pc_loss_sdf'] = sdf_loss.detach()
         return sdf_loss * (self.conf.get_float('pc_weight.weight') if 'pc_weight' in self.conf else 60.)
@@ -359,7 +359,7 @@ class OptimNetwork(nn.Module):
         c_live = cameras.cam_pos()
         v = v_live.detach()
         p = self.TmpPs
-        f = self.sdf(p, ratio)
+        f = self.sdf(p, ratio, sdf_only=True)
         with mlp_engine.input_grads_only():
             grad_f_p = torch.autograd.grad(f, p, torch.ones_like(f), retain_graph=False)[0]
         d = self.deformer(p, defconds, self.batch_inds, ratio=ratio)
@@ -374,7 +374,7 @@ class OptimNetwork(nn.Module):
         # The reference builds a surrogate loss sum(param * grad) from three autograd.grad calls and back-propagates it
         # (network.py:773-814); that adds `grad` to every parameter's .grad, which is exactly one backward of
         # (f, d) with the cotangents (-rhs_f, temp).
-        f2 = self.sdf(p.detach(), ratio)
+        f2 = self.sdf(p.detach(), ratio, sdf_only=True)
         d2 = self.deformer(p.detach(), defconds, self.batch_inds, ratio=ratio)
         temp = (rhs_1[:, :, -3:].matmul(-v_cross)).view(-1, 3)
         outs, cots = [f2, d2], [(-rhs_1[:, :, 0]).reshape(f2.shape).detach(), temp.detach()]

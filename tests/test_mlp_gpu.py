@@ -166,3 +166,20 @@ def test_engine_group4_tangents_and_reverse():
     v0 = net.lin0.weight_v.detach().clone().requires_grad_(True); g0 = net.lin0.weight_g.detach()
     torch._weight_norm(v0, g0, 0).backward(dWs[0][:, :39])
     close(v0.grad, ref[2], 1e-3, 1e-4 * float(ref[2].abs().max()))
+
+
+def test_sdf_only_variant_matches_full_network():
+    from selfreconcode_amd import mlp_engine
+    net = _sdf(21)
+    x = fx.det_tensor((300, 3), 5, 0.8).to(DEV).requires_grad_(True)
+    full = net(x, 0.8)
+    g_full = torch.autograd.grad(full.abs().sum(), [x, net.lin8.weight_v, net.lin8.bias, net.lin2.weight_v])
+    only = net(x, 0.8, sdf_only=True)
+    assert net.rendcond is None and only.shape == (300, 1)
+    g_only = torch.autograd.grad(only.abs().sum(), [x, net.lin8.weight_v, net.lin8.bias, net.lin2.weight_v])
+    close(only, full, 1e-6, 1e-7)
+    for a, b in zip(g_only, g_full):
+        close(a, b, 1e-5, 1e-6 * max(1.0, float(b.abs().max())))
+    # tiny batches take the 64x64-tile kernel: same numbers
+    xs = x.detach()[:37].clone().requires_grad_(True)
+    close(net(xs, 0.8), full[:37], 1e-6, 1e-7)
