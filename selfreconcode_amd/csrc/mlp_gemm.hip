@@ -442,20 +442,33 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
   const int ncols = a->N + (a->mode == SR_EPI_FWD ? a->naux_fwd : 0);
   sr_gemm_args g = *a;
   if (g.mode != SR_EPI_FWD) g.naux_fwd = 0;
-  if (g.M <= 4096 && ncols > 32) {
-    // small batches (converged-ray branches, a few hundred to a few thousand rows): a 128x128 tile leaves >90% of the
-    // CUs idle and still costs a full 16-step K loop (~40 us); 64x64 tiles give 4x the workgroups at 1/4 the latency.
-    using C_ = Cfg<2, 2, 1, 1>;
-    const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));
-    hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 1, 1>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), (hipStream_t)stream, g);
-  } else if (ncols <= 32) {
+  // Tile choice: 256 CUs x (workgroups resident per CU) slots; a launch costs ceil(workgroups / slots) rounds of one tile's
+  // latency.  M = 24k rows (the refiner's group-4 batches) is 764 tiles of 128x128 = 1.5 rounds -> 25% of the chip idles
+  // in the second round; 64x128 tiles make it 3.0 rounds of half-size tiles.  Pick the cheapest by this model.
+  if (ncols <= 32) {
     using C_ = Cfg<4, 1, 2, 1>;
     const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));
     hipLaunchKernelGGL((gemm_nt_kernel<4, 1, 2, 1>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), (hipStream_t)stream, g);
   } else {
-    using C_ = Cfg<2, 2, 2, 2>;
-    const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));
-    hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), (hipStream_t)stream, g);
+    auto cost = [&](int bm, int bn, int per_cu, double eff) {
+      const double wgs = (double)sr_cdiv(g.M, bm) * (double)sr_cdiv(ncols, bn);
+      const double rounds = (double)sr_cdiv((int64_t)wgs, 256 * per_cu);
+      return rounds * bm * bn / eff;
+    };
+    const double c128 = cost(128, 128, 2, 1.0), c64x128 = cost(64, 128, 2, 0.92), c64 = cost(64, 64, 4, 0.75);
+    if (c64 < c128 && c64 < c64x128) {
+      using C_ = Cfg<2, 2, 1, 1>;
+      const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));
+      hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 1, 1>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), (hipStream_t)stream, g);
+    } else if (c64x128 < c128) {
+      using C_ = Cfg<2, 2, 1, 2>;
+      const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));
+      hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 1, 2>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), (hipStream_t)stream, g);
+    } else {
+      using C_ = Cfg<2, 2, 2, 2>;
+      const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));
+      hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), (hipStream_t)stream, g);
+    }
   }
   return sr_launch_status();
 }
