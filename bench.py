@@ -119,7 +119,7 @@ def main():
                    "rasterisation": "in-repo stand-ins (vertex z-buffer seeds + soft point splat); pytorch3d is third-party, not in the reference repo",
                    "parallelism": f"frame-parallel dp{world}: one flat grad all-reduce/step + template-vertex grad all-reduce"},
         "sdf_mlp_gsamples_per_s": round(sdf_gs, 5),
-        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<2,2,2,2> (fp32 MFMA 32x32x2 layer GEMM, fused epilogue)",
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (fp32 MFMA 32x32x2 layer GEMM with fused epilogue; 128x128 / 64x128 / 64x64 tiles), all launches with >= 128 rows",
                      "achieved": prof["tflops"], "peak": 157.3, "unit": "TFLOP/s", "frac": round(prof["tflops"] / 157.3, 4),
                      "launches": prof["launches"], "avg_launch_us": prof["avg_us"], "flop_per_launch": prof["avg_flop"],
                      "traffic": None},
