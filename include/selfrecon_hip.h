@@ -194,6 +194,25 @@ typedef struct {
 } sr_newton_args;
 int sr_newton_update(const sr_newton_args* host_args, void* stream);
 
+/* Reverse-mode form of the same refiner step (utils/FindSurfacePs.py:135-151): `sr_newton_prepare` tests convergence and
+ * emits t = J_lbs^T (d sin-angle / d y) as the cotangent rows of the deformation offset ([M, ld_t], columns >= 3 zeroed;
+ * t_out == NULL: convergence test only); after the two reverse sweeps `sr_newton_apply` forms
+ * g = w1 sign(f) grad_f + w2 (t + grad_off) and steps the unconverged points. */
+typedef struct {
+  int64_t M;
+  const float* sdf; int64_t ld_sdf;      /* f = sdf[i*ld_sdf] */
+  const float* y; const float* jlbs;     /* LBS output [M,3] and dLBS/dq [M,3,3] */
+  const float* rays; const float* cam;
+  uint8_t* converged;                    /* [M] written by prepare, read by apply */
+  float* t_out; int64_t ld_t; float* s_out;
+  const float* grad_f; const float* grad_off;   /* [M,3] each (apply) */
+  const float* p; float* p_out;          /* (apply) */
+  float dthreshold, athreshold, w1, w2;
+} sr_newton2_args;
+int sr_newton_prepare(const sr_newton2_args* host_args, void* stream);
+int sr_newton_apply(const sr_newton2_args* host_args, void* stream);
+
+
 /* ---------------------------------------------------------------- MCGpu (a17)
  * Replaces MCGpu/MCGpu.cpp:20-56 mc_gpu -> MCGpu::init/MC/scaleVertices (CudaKernels.cu:524-639) and
  * kernels K6-K9.  Two calls because the output sizes are data dependent (the reference also copies

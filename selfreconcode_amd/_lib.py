@@ -43,6 +43,12 @@ class SrNewtonArgs(ctypes.Structure):
                 ("dthreshold", ctypes.c_float), ("athreshold", ctypes.c_float), ("w1", ctypes.c_float), ("w2", ctypes.c_float)]
 
 
+class SrNewton2Args(ctypes.Structure):
+    _fields_ = [("M", _i64), ("sdf", _vp), ("ld_sdf", _i64), ("y", _vp), ("jlbs", _vp), ("rays", _vp), ("cam", _vp), ("converged", _vp),
+                ("t_out", _vp), ("ld_t", _i64), ("s_out", _vp), ("grad_f", _vp), ("grad_off", _vp), ("p", _vp), ("p_out", _vp),
+                ("dthreshold", ctypes.c_float), ("athreshold", ctypes.c_float), ("w1", ctypes.c_float), ("w2", ctypes.c_float)]
+
+
 class SrError(RuntimeError):
     pass
 
@@ -76,6 +82,8 @@ SIGNATURES = {
     "sr_lbs_fwd": [_vp, _vp],
     "sr_lbs_bwd": [_vp, _vp, _vp, _vp, _vp, _vp],
     "sr_newton_update": [_vp, _vp],
+    "sr_newton_prepare": [_vp, _vp],
+    "sr_newton_apply": [_vp, _vp],
     "sr_mc_workspace_bytes": [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32],
     "sr_mc_count": [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp],
     "sr_mc_emit": [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp] + [ctypes.c_float] * 6 + [_vp, _vp, _vp],

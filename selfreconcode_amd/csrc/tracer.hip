@@ -60,3 +60,67 @@ extern "C" int sr_newton_update(const sr_newton_args* a, void* stream) {
   hipLaunchKernelGGL(newton_kernel, dim3(sr_stream_grid(a->M, 256)), dim3(256), 0, (hipStream_t)stream, *a);
   return sr_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Reverse-mode variant of the refiner step: the SDF gradient and the deformer vector-Jacobian product come from
+// one reverse sweep each over group-1 activations (2x the rows of a value pass) instead of a group-4 forward (4x).
+//   prepare: convergence test + cotangent t = J_lbs^T (d s / d y) of the deformation offset, written as rows [M, ld_t]
+//   apply  : g = w1 sign(f) grad_f + w2 (t + J_off^T t),  p <- p - L g / |g|^2
+namespace {
+__global__ __launch_bounds__(256) void newton_prepare_kernel(sr_newton2_args g) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < g.M; i += (int64_t)gridDim.x * blockDim.x) {
+    const float f = g.sdf[i * g.ld_sdf];
+    const float vx = g.rays[i * 3], vy = g.rays[i * 3 + 1], vz = g.rays[i * 3 + 2];
+    const float dx = g.y[i * 3] - g.cam[0], dy = g.y[i * 3 + 1] - g.cam[1], dz = g.y[i * 3 + 2] - g.cam[2];
+    const float ux = dy * vz - dz * vy, uy = dz * vx - dx * vz, uz = dx * vy - dy * vx;
+    const float un = sqrtf(ux * ux + uy * uy + uz * uz), dn = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float s = un / dn;
+    g.converged[i] = ((fabsf(f) < g.dthreshold) && (asinf(s) * 180.0f / 3.14159265358979323846f < g.athreshold)) ? 1 : 0;
+    if (!g.t_out) continue;
+    const float iu = un > 0.f ? 1.f / un : 0.f;
+    const float hx = ux * iu, hy = uy * iu, hz = uz * iu;
+    const float ex = (vy * hz - vz * hy) / dn - un * dx / (dn * dn * dn);
+    const float ey = (vz * hx - vx * hz) / dn - un * dy / (dn * dn * dn);
+    const float ez = (vx * hy - vy * hx) / dn - un * dz / (dn * dn * dn);
+    const float* jl = g.jlbs + i * 9;
+    float* t = g.t_out + i * g.ld_t;
+    t[0] = jl[0] * ex + jl[3] * ey + jl[6] * ez;
+    t[1] = jl[1] * ex + jl[4] * ey + jl[7] * ez;
+    t[2] = jl[2] * ex + jl[5] * ey + jl[8] * ez;
+    for (int c = 3; c < g.ld_t; ++c) t[c] = 0.f;
+    g.s_out[i] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void newton_apply_kernel(sr_newton2_args g) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < g.M; i += (int64_t)gridDim.x * blockDim.x) {
+    if (g.converged[i]) { g.p_out[i * 3] = g.p[i * 3]; g.p_out[i * 3 + 1] = g.p[i * 3 + 1]; g.p_out[i * 3 + 2] = g.p[i * 3 + 2]; continue; }
+    const float f = g.sdf[i * g.ld_sdf];
+    const float sg = f > 0.f ? 1.f : (f < 0.f ? -1.f : 0.f);
+    const float* t = g.t_out + i * g.ld_t;
+    float gv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gv[c] = g.w1 * sg * g.grad_f[i * 3 + c] + g.w2 * (t[c] + g.grad_off[i * 3 + c]);
+    const float L = g.w1 * fabsf(f) + g.w2 * g.s_out[i];
+    const float st = -L / (gv[0] * gv[0] + gv[1] * gv[1] + gv[2] * gv[2]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g.p_out[i * 3 + c] = g.p[i * 3 + c] + st * gv[c];
+  }
+}
+}  // namespace
+
+extern "C" int sr_newton_prepare(const sr_newton2_args* a, void* stream) {
+  if (!a || a->M < 0) return SR_EINVAL;
+  if (a->M == 0) return SR_OK;
+  if (!a->sdf || !a->y || !a->rays || !a->cam || !a->converged) return SR_EINVAL;
+  if (a->t_out && (!a->jlbs || !a->s_out || a->ld_t < 3)) return SR_EINVAL;
+  hipLaunchKernelGGL(newton_prepare_kernel, dim3(sr_stream_grid(a->M, 256)), dim3(256), 0, (hipStream_t)stream, *a);
+  return sr_launch_status();
+}
+extern "C" int sr_newton_apply(const sr_newton2_args* a, void* stream) {
+  if (!a || a->M < 0) return SR_EINVAL;
+  if (a->M == 0) return SR_OK;
+  if (!a->sdf || !a->converged || !a->t_out || !a->s_out || !a->grad_f || !a->grad_off || !a->p || !a->p_out) return SR_EINVAL;
+  hipLaunchKernelGGL(newton_apply_kernel, dim3(sr_stream_grid(a->M, 256)), dim3(256), 0, (hipStream_t)stream, *a);
+  return sr_launch_status();
+}

@@ -162,3 +162,24 @@ def test_kinematic_chain_kernel_vs_oracle():
     close(A, Ao, atol=2e-6); close(G[:, :, :3, 3], newJ, atol=2e-6)
     ours = torch.autograd.grad((A * ca.to(DEV)).sum() + (G[:, :, :3, 3] * cj.to(DEV)).sum(), pg)[0]
     close(ours, ref, 2e-4, 2e-5)
+
+
+def test_refiner_forward_and_reverse_mode_agree(golden):
+    """the group-4 (forward tangents) and the reverse-sweep formulations of the Newton step give the same refinement."""
+    from selfreconcode_amd.utils import FindSurfacePs as F
+    from selfreconcode_amd.model.network import getTmpSdf
+    g, gl, gt = golden("tracer"), golden("lbs"), golden("translator")
+    comp = _composite(last_scale=0.05)
+    sph = getTmpSdf(DEV, 6, 0.6, 256)
+    sph.load_state_dict(fx.sphere_sdf_params(7), strict=True)
+    defconds = [gt["conds"].to(DEV), [gl["poses"].to(DEV), gl["trans"].to(DEV)]]
+    outs = []
+    for mode in (False, True):
+        F.REVERSE_MODE = mode
+        ps, ok = F.OptimizeSurfacePs(g["campos"].to(DEV), g["rays"].to(DEV), g["p0"].to(DEV).clone(), g["bi"].to(DEV), sph, RATIO, comp, defconds,
+                                     dthreshold=5.e-5, athreshold=0.04, w1=3.05, w2=1., times=10)
+        outs.append((ps.cpu(), ok.cpu()))
+    F.REVERSE_MODE = True
+    close(outs[0][0], outs[1][0], rtol=0, atol=1e-5)
+    close(outs[1][0], g["ps"], rtol=0, atol=2e-5)
+    assert (outs[0][1] == outs[1][1]).float().mean() > 0.97
