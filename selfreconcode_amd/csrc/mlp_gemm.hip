@@ -276,7 +276,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(sr_gemm_tn_args g, int row
   __shared__ __attribute__((aligned(16))) float Xs[2][TBR * TLD];
   const int tiles_k = (g.K + 127) / 128;
   const int tiles_n = (g.N + 127) / 128;
-  const int tile = blockIdx.x % (tiles_k * tiles_n), split = blockIdx.x / (tiles_k * tiles_n);
+  // XCD-aware order: workgroup b runs on XCD b % 8 with a private L2.  The tiles of one row-slice (split) all read the
+  // same Z and A rows, so give each XCD whole splits: virtual id = xcd * (grid/8) + b / 8.  (Before: the 4 k-tiles /
+  // 4 n-tiles of a slice sat on different XCDs and every operand row was streamed from HBM 4 times.)
+  int vb = blockIdx.x;
+  if ((gridDim.x & 7) == 0) vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int tile = vb % (tiles_k * tiles_n), split = vb / (tiles_k * tiles_n);
   const int n0 = (tile / tiles_k) * 128, k0 = (tile % tiles_k) * 128;
   const int r_begin = split * rows_per_split;
   const int r_end = min(g.R, r_begin + rows_per_split);
@@ -344,14 +349,24 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(sr_gemm_tn_args g, int row
     if (t + 1 < nsteps) load(r_begin + (t + 1) * TBR);
     const float* zb = &Zs[cur][kh * TLD + wm * 64 + li];
     const float* xb = &Xs[cur][kh * TLD + wn * 64 + li];
+    // fragment reads are issued in blocks of 4 row pairs ahead of their 16 MFMAs (the compiler otherwise reuses one
+    // register quad and exposes an LDS round trip every 4 MFMAs)
 #pragma unroll
-    for (int e = 0; e < TBR / 2; ++e) {  // rows 2e + kh
-      const float z0 = zb[2 * e * TLD], z1 = zb[2 * e * TLD + 32];
-      const float x0 = xb[2 * e * TLD], x1 = xb[2 * e * TLD + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0, x0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0, x1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1, x0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1, x1, acc[1][1], 0, 0, 0);
+    for (int h = 0; h < TBR / 8; ++h) {
+      float z0[4], z1[4], x0[4], x1[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 2 * (h * 4 + e) * TLD;
+        z0[e] = zb[r]; z1[e] = zb[r + 32]; x0[e] = xb[r]; x1[e] = xb[r + 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0[e], x0[e], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0[e], x1[e], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1[e], x0[e], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1[e], x1[e], acc[1][1], 0, 0, 0);
+      }
     }
     if (do_bias) {
       const int rbase = r_begin + t * TBR;

@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256) void raster_pass1(const float* __restrict__ pi
         float b0, b1, b2, d;
         if (!bary_of(t, (float)x, (float)y, b0, b1, b2, d)) continue;
         const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned int)f;
-        atomicMin(zbuf + (img * H + y) * W + x, key);
+        unsigned long long* slot = zbuf + (img * H + y) * W + x;
+        if (key < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, key);   // most fragments lose: skip the RMW
       }
   }
 }

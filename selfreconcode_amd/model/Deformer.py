@@ -298,10 +298,13 @@ class _PosedChain(torch.autograd.Function):
         ctx.skin = skin
         ctx.save_for_backward(p)
         ctx.pshape = poses.shape
+        ctx.set_materialize_grads(False)
         return G, A
 
     @staticmethod
     def backward(ctx, Gbar, Abar):
+        if Gbar is None and Abar is None:
+            return None, None
         (p,) = ctx.saved_tensors
         js, pa, ip = ctx.skin._host_consts()
         out = torch.empty_like(p)
@@ -369,6 +372,7 @@ class TranslatorValueJacobian(torch.autograd.Function):
         d = flat + out[:, 0]
         J = out[:, 1:4].transpose(1, 2) + torch.eye(3, device=flat.device)         # J[p, r, c] = delta + d off_r / d x_c
         ctx.tr, ctx.wt, ctx.segment, ctx.n_extra, ctx.xshape = tr, wt, segment, cd.shape[0], x.shape
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(flat, index, A0, *wb, *acts[:-1])
         return d.view(x.shape), J
 
@@ -382,6 +386,8 @@ class TranslatorValueJacobian(torch.autograd.Function):
         wb, acts = saved[3:3 + 2 * nl], list(saved[3 + 2 * nl:])
         Ws = list(wb[:nl])
         P = flat.shape[0]
+        if dbar is None and Jbar is None:
+            return (None,) * (6 + 2 * nl)
         ybar = torch.zeros((P, 4, 4), dtype=torch.float32, device=flat.device)
         if dbar is not None:
             ybar[:, 0, :3] = dbar.reshape(-1, 3)

@@ -296,7 +296,9 @@ class OptimNetwork(nn.Module):
             else:
                 weights = torch.ones(nx.shape[0], device=device)
             gtnormals = datas['normal'].to(device)[self.batch_inds, self.row_inds, self.col_inds, :]
-            flip = torch.tensor([[-1., 0., 0.], [0., 1., 0.], [0., 0., -1.]], device=device)
+            if getattr(self, "_flip", None) is None or self._flip.device != device:
+                self._flip = torch.tensor([[-1., 0., 0.], [0., 1., 0.], [0., 0., -1.]], device=device)      # cached: an H2D copy is a sync point
+            flip = self._flip
             gtnormals = ((cameras.R[0] @ flip) @ gtnormals.view(-1, 3, 1)).view(-1, 3)
             gtnorms = gtnormals.norm(dim=1, keepdim=True)
             valid_mask = (gtnorms > 0.0001)[..., 0]
