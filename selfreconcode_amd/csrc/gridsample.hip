@@ -76,6 +76,11 @@ struct PointIdx {
 };
 __device__ __forceinline__ PointIdx split(int64_t idx, const sr_tensor5& g) {
   PointIdx p;
+  if ((g.size[1] | g.size[2]) == 1 && idx <= 0xffffffffll && g.size[3] <= 0xffffffffll) {   // the usual [N,1,1,P,3] grid: one u32 division
+    const uint32_t n = (uint32_t)idx / (uint32_t)g.size[3];
+    p.n = n; p.d = 0; p.h = 0; p.w = (uint32_t)idx - n * (uint32_t)g.size[3];
+    return p;
+  }
   p.w = idx % g.size[3];
   p.h = (idx / g.size[3]) % g.size[2];
   p.d = (idx / (g.size[2] * g.size[3])) % g.size[1];
@@ -240,6 +245,108 @@ __global__ __launch_bounds__(256) void gs_dbwd_kernel(int64_t total, const T* __
   }
 }
 
+
+// ---- channel-last fast path (fp32, input stride[1] == 1, C % 4 == 0): a corner's channels are one contiguous run, read
+// as float4.  This is the layout the host keeps for the skinning-weight volume.  The loop is corner-major -- a corner's
+// 16*CV-byte run is consumed in one go while its cache lines are hot, with 4*CV channel accumulators in registers -- and
+// passes over the channels in slabs of 4*CV.  Per channel the corners are still summed in the order k = 0..7, so the
+// forward value is bit-identical to the generic kernel.
+typedef float gs_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CV>
+__global__ __launch_bounds__(256) void gs_fwd_cl_kernel(int64_t total, const float* __restrict__ input, sr_tensor5 in_d,
+                                                         const float* __restrict__ grid, sr_tensor5 g_d, float* __restrict__ out,
+                                                         sr_tensor5 o_d) {
+  const int64_t C = in_d.size[1], D = in_d.size[2], H = in_d.size[3], W = in_d.size[4];
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const PointIdx p = split(idx, g_d);
+    const float* gp = grid + p.n * g_d.stride[0] + p.d * g_d.stride[1] + p.h * g_d.stride[2] + p.w * g_d.stride[3];
+    float ix = safe_int_range(clip_fwd(unnormalize(gp[0], W), W));
+    float iy = safe_int_range(clip_fwd(unnormalize(gp[g_d.stride[4]], H), H));
+    float iz = safe_int_range(clip_fwd(unnormalize(gp[2 * g_d.stride[4]], D), D));
+    Corner c; Weights<float> w;
+    setup(ix, iy, iz, W, H, D, c, w);
+    const float* ip = input + p.n * in_d.stride[0];
+    float* op = out + p.n * o_d.stride[0] + p.d * o_d.stride[2] + p.h * o_d.stride[3] + p.w * o_d.stride[4];
+    for (int64_t ch = 0; ch < C; ch += 4 * CV) {
+      gs_f32x4 acc[CV];
+#pragma unroll
+      for (int v = 0; v < CV; ++v) acc[v] = gs_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (!c.inb[k]) continue;
+        const float wk = w.wx[k & 1] * w.wy[(k >> 1) & 1] * w.wz[k >> 2];
+        const gs_f32x4* src = reinterpret_cast<const gs_f32x4*>(ip + (int64_t)(c.z0 + (k >> 2)) * in_d.stride[2] +
+                                                                (int64_t)(c.y0 + ((k >> 1) & 1)) * in_d.stride[3] +
+                                                                (int64_t)(c.x0 + (k & 1)) * in_d.stride[4] + ch);
+#pragma unroll
+        for (int v = 0; v < CV; ++v) acc[v] += src[v] * wk;
+      }
+#pragma unroll
+      for (int v = 0; v < CV; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) op[(ch + 4 * v + e) * o_d.stride[1]] = acc[v][e];
+    }
+  }
+}
+
+// grad_grid only (the volume is a buffer): the gin == NULL case of gs_bwd_kernel.  Per corner the channel dot product
+// d_k = sum_c I_c[k] gO_c is formed first, then GG_a = sum_k d_a w_k * d_k.
+template <int CV>
+__global__ __launch_bounds__(256) void gs_bwd_cl_kernel(int64_t total, const float* __restrict__ input, sr_tensor5 in_d,
+                                                         const float* __restrict__ grid, sr_tensor5 g_d, const float* __restrict__ gout,
+                                                         sr_tensor5 go_d, float* __restrict__ ggrid) {
+  const int64_t C = in_d.size[1], D = in_d.size[2], H = in_d.size[3], W = in_d.size[4];
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const PointIdx p = split(idx, g_d);
+    const float* gp = grid + p.n * g_d.stride[0] + p.d * g_d.stride[1] + p.h * g_d.stride[2] + p.w * g_d.stride[3];
+    float mx, my, mz;
+    float ix = safe_int_range(clip_grad(unnormalize(gp[0], W), W, &mx));
+    float iy = safe_int_range(clip_grad(unnormalize(gp[g_d.stride[4]], H), H, &my));
+    float iz = safe_int_range(clip_grad(unnormalize(gp[2 * g_d.stride[4]], D), D, &mz));
+    Corner c; Weights<float> w;
+    setup(ix, iy, iz, W, H, D, c, w);
+    const float* ip = input + p.n * in_d.stride[0];
+    const float* gop = gout + p.n * go_d.stride[0] + p.d * go_d.stride[2] + p.h * go_d.stride[3] + p.w * go_d.stride[4];
+    float gix = 0.f, giy = 0.f, giz = 0.f;
+    for (int64_t ch = 0; ch < C; ch += 4 * CV) {
+      float go[4 * CV];
+#pragma unroll
+      for (int e = 0; e < 4 * CV; ++e) go[e] = gop[(ch + e) * go_d.stride[1]];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (!c.inb[k]) continue;
+        const gs_f32x4* src = reinterpret_cast<const gs_f32x4*>(ip + (int64_t)(c.z0 + (k >> 2)) * in_d.stride[2] +
+                                                                (int64_t)(c.y0 + ((k >> 1) & 1)) * in_d.stride[3] +
+                                                                (int64_t)(c.x0 + (k & 1)) * in_d.stride[4] + ch);
+        float dot = 0.f;
+#pragma unroll
+        for (int v = 0; v < CV; ++v) {
+          const gs_f32x4 c4 = src[v];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dot += c4[e] * go[4 * v + e];
+        }
+        const float sx = (k & 1) ? 1.f : -1.f, sy = ((k >> 1) & 1) ? 1.f : -1.f, sz = (k >> 2) ? 1.f : -1.f;
+        gix += sx * (w.wy[(k >> 1) & 1] * w.wz[k >> 2] * dot);
+        giy += sy * (w.wx[k & 1] * w.wz[k >> 2] * dot);
+        giz += sz * (w.wx[k & 1] * w.wy[(k >> 1) & 1] * dot);
+      }
+    }
+    gix = (float)((double)(gix * (float)W) / 2.0);
+    giy = (float)((double)(giy * (float)H) / 2.0);
+    giz = (float)((double)(giz * (float)D) / 2.0);
+    float* gg = ggrid + idx * 3;
+    gg[0] = mx * gix; gg[1] = my * giy; gg[2] = mz * giz;
+  }
+}
+
+inline int channel_slab(int64_t C) { return C % 24 == 0 ? 6 : C % 16 == 0 ? 4 : C % 8 == 0 ? 2 : 1; }
+
+inline bool channel_last_ok(const void* input, const sr_tensor5& in_d) {
+  return in_d.stride[1] == 1 && (in_d.size[1] & 3) == 0 && ((uintptr_t)input & 15) == 0 && (in_d.stride[0] & 3) == 0 &&
+         (in_d.stride[2] & 3) == 0 && (in_d.stride[3] & 3) == 0 && (in_d.stride[4] & 3) == 0;
+}
+
 bool valid_desc(const sr_tensor5& in_d, const sr_tensor5& g_d) {
   if (in_d.size[0] != g_d.size[0] || g_d.size[4] != 3) return false;
   for (int i = 0; i < 5; ++i)
@@ -255,6 +362,21 @@ int gs_fwd(const T* input, sr_tensor5 in_d, const T* grid, sr_tensor5 g_d, T* ou
   const int64_t total = g_d.size[0] * g_d.size[1] * g_d.size[2] * g_d.size[3];
   if (total == 0 || in_d.size[1] == 0) return SR_OK;
   if (!input || !grid || !out) return SR_EINVAL;
+  if constexpr (sizeof(T) == 4) {
+    if (channel_last_ok(input, in_d)) {
+#define SR_GS_FWD_CL(CV)                                                                                                          \
+  hipLaunchKernelGGL(gs_fwd_cl_kernel<CV>, dim3(sr_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, total, (const float*)input, \
+                     in_d, (const float*)grid, g_d, (float*)out, o_d)
+      switch (channel_slab(in_d.size[1])) {
+        case 6: SR_GS_FWD_CL(6); break;
+        case 4: SR_GS_FWD_CL(4); break;
+        case 2: SR_GS_FWD_CL(2); break;
+        default: SR_GS_FWD_CL(1); break;
+      }
+#undef SR_GS_FWD_CL
+      return sr_launch_status();
+    }
+  }
   hipLaunchKernelGGL(gs_fwd_kernel<T>, dim3(sr_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, total, input, in_d, grid, g_d, out, o_d);
   return sr_launch_status();
 }
@@ -265,6 +387,21 @@ int gs_bwd(const T* input, sr_tensor5 in_d, const T* grid, sr_tensor5 g_d, const
   const int64_t total = g_d.size[0] * g_d.size[1] * g_d.size[2] * g_d.size[3];
   if (total == 0) return SR_OK;
   if (!input || !grid || !gout || !ggrid) return SR_EINVAL;
+  if constexpr (sizeof(T) == 4) {
+    if (!gin && channel_last_ok(input, in_d)) {
+#define SR_GS_BWD_CL(CV)                                                                                                          \
+  hipLaunchKernelGGL(gs_bwd_cl_kernel<CV>, dim3(sr_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, total, (const float*)input, \
+                     in_d, (const float*)grid, g_d, (const float*)gout, go_d, (float*)ggrid)
+      switch (channel_slab(in_d.size[1])) {
+        case 6: SR_GS_BWD_CL(6); break;
+        case 4: SR_GS_BWD_CL(4); break;
+        case 2: SR_GS_BWD_CL(2); break;
+        default: SR_GS_BWD_CL(1); break;
+      }
+#undef SR_GS_BWD_CL
+      return sr_launch_status();
+    }
+  }
   hipLaunchKernelGGL(gs_bwd_kernel<T>, dim3(sr_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, total, input, in_d, grid, g_d, gout, go_d, gin, gi_d, ggrid);
   return sr_launch_status();
 }

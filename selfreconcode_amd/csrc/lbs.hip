@@ -9,6 +9,7 @@
 // channels_last_3d format), so a corner is one contiguous 96-byte run read as 6 float4.
 // Gather-bound: 8 x 96 B per point from a 181 MB volume that sits in the 256 MB Infinity Cache.
 #include "sr_common.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -118,6 +119,21 @@ __global__ __launch_bounds__(256) void lbs_fwd_kernel(sr_lbs_args g) {
   }
 }
 
+// Sum of v over the 64 lanes of a fully active wave: four DPP steps fold each row of 16 lanes, the four row totals are
+// read back as scalars.  Every lane returns the same value.
+__device__ __forceinline__ float wave_sum(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+  const int b = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+}
+
 // Backward of y = LBS(p) for a cotangent ybar [P,3]:  pbar = J^T ybar (analytic Jacobian incl. the sampler term),
 // Abar[frame][j] += w_j ybar (x) [p;1],  transbar[frame] += ybar.  Per-workgroup partial sums of Abar / transbar
 // live in LDS and are flushed with one atomicAdd per entry (Guideline 12: reduce first, then one atomic per block).
@@ -139,7 +155,11 @@ __global__ __launch_bounds__(256) void lbs_bwd_kernel(sr_lbs_args g, const float
       const int frame = g.batch_inds ? (int)g.batch_inds[idx] : (int)(idx / g.points_per_frame);
       const float* Af = g.A + (int64_t)frame * NJ * 12;
       float* acc = sacc + frame * per;
-      float w[NJ], s[NJ];                           // weights and s_j = ybar . (A_j [p;1])
+      float w[NJ], s[NJ];
+      // a full wave whose 64 points share one frame sums its contributions in registers (DPP) and issues ONE LDS atomic
+      // per word; ragged / mixed-frame waves keep the per-lane LDS atomics
+      const bool full_wave = base + (int64_t)(threadIdx.x | 63) < g.P;
+      const bool uniform = full_wave && __all(frame == __builtin_amdgcn_readfirstlane(frame));                           // weights and s_j = ybar . (A_j [p;1])
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const float* a = Af + j * 12;
@@ -178,12 +198,28 @@ __global__ __launch_bounds__(256) void lbs_bwd_kernel(sr_lbs_args g, const float
         if (Abar) {
           const float wj = w[j];
           float* o = acc + j * 12;
-          atomicAdd(o + 0, wj * bx * px); atomicAdd(o + 1, wj * bx * py); atomicAdd(o + 2, wj * bx * pz); atomicAdd(o + 3, wj * bx);
-          atomicAdd(o + 4, wj * by * px); atomicAdd(o + 5, wj * by * py); atomicAdd(o + 6, wj * by * pz); atomicAdd(o + 7, wj * by);
-          atomicAdd(o + 8, wj * bz * px); atomicAdd(o + 9, wj * bz * py); atomicAdd(o + 10, wj * bz * pz); atomicAdd(o + 11, wj * bz);
+          const float c12[12] = {wj * bx * px, wj * bx * py, wj * bx * pz, wj * bx, wj * by * px, wj * by * py, wj * by * pz, wj * by,
+                                 wj * bz * px, wj * bz * py, wj * bz * pz, wj * bz};
+          if (uniform) {          // all 64 lanes hit the same 12 words: butterfly-sum in registers, ONE LDS atomic per word per wave
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+              const float v = wave_sum(c12[e]);
+              if ((threadIdx.x & 63) == 0) atomicAdd(o + e, v);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 12; ++e) atomicAdd(o + e, c12[e]);
+          }
         }
       }
-      if (tbar) { atomicAdd(acc + NJ * 12, bx); atomicAdd(acc + NJ * 12 + 1, by); atomicAdd(acc + NJ * 12 + 2, bz); }
+      if (tbar) {
+        if (uniform) {
+          const float sx = wave_sum(bx), sy = wave_sum(by), sz = wave_sum(bz);
+          if ((threadIdx.x & 63) == 0) { atomicAdd(acc + NJ * 12, sx); atomicAdd(acc + NJ * 12 + 1, sy); atomicAdd(acc + NJ * 12 + 2, sz); }
+        } else {
+          atomicAdd(acc + NJ * 12, bx); atomicAdd(acc + NJ * 12 + 1, by); atomicAdd(acc + NJ * 12 + 2, bz);
+        }
+      }
       if (pbar) {
         pbar[idx * 3 + 0] = T[0] * bx + T[3] * by + T[6] * bz + gu * ax.du;
         pbar[idx * 3 + 1] = T[1] * bx + T[4] * by + T[7] * bz + gv * ay.du;

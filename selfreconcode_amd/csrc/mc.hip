@@ -9,8 +9,12 @@
 // (cell, triangle) -- bit-reproducible, and equal to the reference after canonicalisation.
 //
 // Traffic: classify reads the volume once (4 B/voxel, rows along k are contiguous so a wave reads
-// coalesced 256-byte runs) and writes two u32 counters per voxel; the reference rewrites a
-// 12 B/voxel edge table on every call (K8).  HBM-bound.
+// coalesced 256-byte runs) and writes ONE byte per voxel (owned-edge mask | triangle count << 3)
+// plus two u32 sums per 64-voxel group (a wave = a group; sums come from ballots).  Only the group
+// sums are scanned (n/64 elements).  Emit walks the scanned group offsets (8 B per 64 voxels),
+// skips empty groups wave-uniformly and touches the volume again only for surface cells; ids of
+// neighbour-owned vertices are group offset + popcount over the group's 64 code bytes.  The
+// reference rewrites a 12 B/voxel edge table on every call (K8).  HBM-bound: ~5.3 B/voxel.
 #include "sr_common.h"
 #include "mc_tables.h"
 
@@ -37,20 +41,70 @@ __device__ __forceinline__ int owned_mask(float v0, float vx, float vy, float vz
   return ((b0 != (vx < iso)) ? 1 : 0) | ((b0 != (vy < iso)) ? 2 : 0) | ((b0 != (vz < iso)) ? 4 : 0);
 }
 
-__global__ __launch_bounds__(256) void mc_classify_kernel(const float* __restrict__ sdf, Dim d, float iso, uint32_t* __restrict__ vcnt,
-                                                           uint32_t* __restrict__ tcnt) {
+// lane i <- lane i+1 across the whole wave (DPP wave_shl:1); lane 63 takes lane 0 of `next`
+__device__ __forceinline__ float from_next_lane(float x, float next) {
+  const int last = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, next));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(last, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+}
+
+// Classification of a 64-cell group is kept as six 64-bit planes (bit l = cell l): planes 0-2 the owned-edge crossing
+// mask (x, y, z lattice edge at the cell origin), planes 3-5 the triangle count (0..5).
+// A wave owns MC_CHUNK consecutive groups: the (i, j, k) split of the flat index costs one pair of divisions per chunk
+// and is carried forward by addition; the next group's k-plane values are loaded one step ahead, and the k+1 plane of a
+// cell is the k plane of the next lane (one DPP move), so a cell costs 4 coalesced loads instead of 8.  Corner signs are
+// wave-wide compare masks, so the owned-edge planes are scalar XORs and a group without a sign change never touches
+// the case table.
+constexpr int MC_CHUNK = 16;
+constexpr int MC_PLANES = 6;
+
+__global__ __launch_bounds__(256) void mc_classify_kernel(const float* __restrict__ sdf, Dim d, float iso, uint64_t* __restrict__ planes,
+                                                           uint32_t* __restrict__ vs64, uint32_t* __restrict__ ts64) {
   const int64_t total = (int64_t)d.NX * d.NY * d.NZ;
-  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (int64_t)gridDim.x * blockDim.x) {
-    const int k = (int)(c % d.NZ), j = (int)((c / d.NZ) % d.NY), i = (int)(c / ((int64_t)d.NZ * d.NY));
-    uint32_t nv = 0, nt = 0;
-    if (i < d.NX - 1 && j < d.NY - 1 && k < d.NZ - 1) {
-      float v[8];
-      const int idx = cube_case(sdf, c, d.NY, d.NZ, iso, v);
-      nt = dTriCount[idx];
-      nv = __popc(owned_mask(v[0], v[1], v[3], v[4], iso));
+  const int64_t G = (total + 63) >> 6;
+  const int64_t sx = (int64_t)d.NY * d.NZ, sy = d.NZ;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { vs64[G] = 0; ts64[G] = 0; }   // scan sentinel: off[G] = total
+  for (int64_t g0 = wave * MC_CHUNK; g0 < G; g0 += nwaves * MC_CHUNK) {
+    int64_t c = (g0 << 6) + lane;
+    const int64_t row = c / d.NZ;
+    int k = (int)(c - row * d.NZ), i = (int)(row / d.NY);
+    int j = (int)(row - (int64_t)i * d.NY);
+    const int64_t gend = (g0 + MC_CHUNK < G) ? g0 + MC_CHUNK : G;
+    bool row_ok = i < d.NX - 1 && j < d.NY - 1;       // c >= total implies i >= NX
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (row_ok) { a0 = sdf[c]; a1 = sdf[c + sx]; a2 = sdf[c + sx + sy]; a3 = sdf[c + sy]; }
+    for (int64_t g = g0; g < gend; ++g, c += 64) {
+      // the group after this one, fetched ahead (also the source of lane 63's k+1 plane)
+      int nk = k + 64, nj = j, ni = i;
+      while (nk >= d.NZ) { nk -= d.NZ; if (++nj == d.NY) { nj = 0; ++ni; } }
+      const bool nrow_ok = ni < d.NX - 1 && nj < d.NY - 1;
+      float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+      if (nrow_ok) { n0 = sdf[c + 64]; n1 = sdf[c + 64 + sx]; n2 = sdf[c + 64 + sx + sy]; n3 = sdf[c + 64 + sy]; }
+      const float b0 = from_next_lane(a0, n0), b1 = from_next_lane(a1, n1), b2 = from_next_lane(a2, n2), b3 = from_next_lane(a3, n3);
+      const uint64_t I = __ballot(row_ok && k < d.NZ - 1);
+      const uint64_t s0 = __ballot(a0 < iso), s1 = __ballot(a1 < iso), s2 = __ballot(a2 < iso), s3 = __ballot(a3 < iso);
+      const uint64_t s4 = __ballot(b0 < iso), s5 = __ballot(b1 < iso), s6 = __ballot(b2 < iso), s7 = __ballot(b3 < iso);
+      const uint64_t mixed = ((s0 ^ s1) | (s0 ^ s2) | (s0 ^ s3) | (s0 ^ s4) | (s0 ^ s5) | (s0 ^ s6) | (s0 ^ s7)) & I;
+      uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
+      if (mixed) {
+        m0 = (s0 ^ s1) & I; m1 = (s0 ^ s3) & I; m2 = (s0 ^ s4) & I;
+        const int idx = (a0 < iso ? 1 : 0) | (a1 < iso ? 2 : 0) | (a2 < iso ? 4 : 0) | (a3 < iso ? 8 : 0) | (b0 < iso ? 16 : 0) |
+                        (b1 < iso ? 32 : 0) | (b2 < iso ? 64 : 0) | (b3 < iso ? 128 : 0);
+        const uint32_t nt = dTriCount[idx];
+        m3 = __ballot(nt & 1) & I; m4 = __ballot(nt & 2) & I; m5 = __ballot(nt & 4) & I;
+      }
+      if (lane < MC_PLANES) {
+        const uint64_t mine = lane == 0 ? m0 : lane == 1 ? m1 : lane == 2 ? m2 : lane == 3 ? m3 : lane == 4 ? m4 : m5;
+        planes[g * MC_PLANES + lane] = mine;
+      }
+      if (lane == 0) {
+        vs64[g] = __popcll(m0) + __popcll(m1) + __popcll(m2);
+        ts64[g] = __popcll(m3) + 2 * __popcll(m4) + 4 * __popcll(m5);
+      }
+      a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+      k = nk; j = nj; i = ni; row_ok = nrow_ok;
     }
-    vcnt[c] = nv;
-    tcnt[c] = nt;
   }
 }
 
@@ -129,60 +183,108 @@ __device__ __forceinline__ float edge_offset(float v1, float v2, float iso) {   
 __constant__ int8_t dEdgeBase[12][4] = {{0, 0, 0, 0}, {1, 0, 0, 1}, {0, 1, 0, 0}, {0, 0, 0, 1}, {0, 0, 1, 0}, {1, 0, 1, 1},
                                         {0, 1, 1, 0}, {0, 0, 1, 1}, {0, 0, 0, 2}, {1, 0, 0, 2}, {1, 1, 0, 2}, {0, 1, 0, 2}};
 
-__global__ __launch_bounds__(256) void mc_emit_kernel(const float* __restrict__ sdf, Dim d, float iso, const uint32_t* __restrict__ voff,
-                                                       const uint32_t* __restrict__ toff, float sx, float sy, float sz, float ox,
-                                                       float oy, float oz, float* __restrict__ verts, int64_t* __restrict__ faces) {
+// id of the vertex on lattice edge (cell oc, direction dir), or -1 when that edge is not crossed / not owned
+__device__ __forceinline__ int64_t vertex_id(const uint64_t* __restrict__ planes, const uint32_t* __restrict__ voff64, int64_t oc, int dir) {
+  const int64_t g = oc >> 6;
+  const int l = (int)(oc & 63);
+  const uint64_t* P = planes + g * MC_PLANES;
+  const uint64_t p0 = P[0], p1 = P[1], p2 = P[2];
+  const uint64_t mine = dir == 0 ? p0 : dir == 1 ? p1 : p2;
+  if (!((mine >> l) & 1)) return -1;
+  const uint64_t lt = (1ull << l) - 1;
+  int cnt = __popcll(p0 & lt) + __popcll(p1 & lt) + __popcll(p2 & lt);
+  if (dir > 0) cnt += (int)((p0 >> l) & 1);
+  if (dir > 1) cnt += (int)((p1 >> l) & 1);
+  return (int64_t)voff64[g] + cnt;
+}
+
+// Emit, step 1.  One lane walks one group: the scanned offsets say whether the group holds any surface cell, the planes
+// say which.  Every output slot is tagged with its producer -- vertex slot v gets key cell*4 + dir (two u32 words in
+// verts[v]), face slot f gets key cell*8 + triangle (faces[f][0]) -- so that steps 2 and 3 run one thread per OUTPUT
+// with all lanes busy.  The keys live in the output buffers themselves; no extra workspace.
+__global__ __launch_bounds__(256) void mc_tag_kernel(Dim d, const uint64_t* __restrict__ planes, const uint32_t* __restrict__ voff64,
+                                                      const uint32_t* __restrict__ toff64, uint32_t* __restrict__ vkeys,
+                                                      int64_t* __restrict__ faces) {
   const int64_t total = (int64_t)d.NX * d.NY * d.NZ;
+  const int64_t G = (total + 63) >> 6;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t vid = voff64[g], tid = toff64[g];
+    if (voff64[g + 1] == vid && toff64[g + 1] == tid) continue;
+    const uint64_t* P = planes + g * MC_PLANES;
+    const uint64_t p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3], p4 = P[4], p5 = P[5];
+    uint64_t todo = p0 | p1 | p2 | p3 | p4 | p5;
+    while (todo) {
+      const int l = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const uint64_t c = ((uint64_t)g << 6) + l;
+      if ((p0 >> l) & 1) { vkeys[vid * 3] = (uint32_t)(c * 4 + 0); vkeys[vid * 3 + 1] = (uint32_t)((c * 4 + 0) >> 32); ++vid; }
+      if ((p1 >> l) & 1) { vkeys[vid * 3] = (uint32_t)(c * 4 + 1); vkeys[vid * 3 + 1] = (uint32_t)((c * 4 + 1) >> 32); ++vid; }
+      if ((p2 >> l) & 1) { vkeys[vid * 3] = (uint32_t)(c * 4 + 2); vkeys[vid * 3 + 1] = (uint32_t)((c * 4 + 2) >> 32); ++vid; }
+      const int nt = (int)(((p3 >> l) & 1) | (((p4 >> l) & 1) << 1) | (((p5 >> l) & 1) << 2));
+      for (int t = 0; t < nt; ++t) faces[(int64_t)(tid + t) * 3] = (int64_t)(c * 8 + t);
+      tid += nt;
+    }
+  }
+}
+
+// Emit, step 2: one thread per vertex.
+__global__ __launch_bounds__(256) void mc_vertex_kernel(const float* __restrict__ sdf, Dim d, float iso, const uint32_t* __restrict__ voff64,
+                                                         float sx, float sy, float sz, float ox, float oy, float oz, float* __restrict__ verts) {
+  const int64_t total = (int64_t)d.NX * d.NY * d.NZ;
+  const int64_t V = voff64[(total + 63) >> 6];
   const int64_t strideX = (int64_t)d.NY * d.NZ, strideY = d.NZ;
-  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (int64_t)gridDim.x * blockDim.x) {
-    const int k = (int)(c % d.NZ), j = (int)((c / d.NZ) % d.NY), i = (int)(c / ((int64_t)d.NZ * d.NY));
-    if (!(i < d.NX - 1 && j < d.NY - 1 && k < d.NZ - 1)) continue;
+  const uint32_t* vkeys = reinterpret_cast<const uint32_t*>(verts);
+  for (int64_t vid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; vid < V; vid += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = (uint64_t)vkeys[vid * 3] | ((uint64_t)vkeys[vid * 3 + 1] << 32);
+    const int64_t c = (int64_t)(key >> 2);
+    const int dir = (int)(key & 3);
+    const int64_t row = c / d.NZ;
+    const int k = (int)(c - row * d.NZ), i = (int)(row / d.NY);
+    const int j = (int)(row - (int64_t)i * d.NY);
+    const float v0 = sdf[c];
+    const float vn = sdf[c + (dir == 0 ? strideX : dir == 1 ? strideY : 1)];
+    float x, y, z;
+    {
+#pragma clang fp contract(off)   // keep (a*b)+c unfused: vertex coordinates are then bit-equal to the C oracle
+    const float fX = (float)i, fY = (float)j, fZ = (float)k;
+    if (dir == 0) {          // cube edge 0: v0 -> v1, direction +x
+      const float t = edge_offset(v0, vn, iso);
+      x = (fX + (0.0f + t * 1.0f)) * sx + ox; y = (fY + (0.0f + t * 0.0f)) * sy + oy; z = (fZ + (0.0f + t * 0.0f)) * sz + oz;
+    } else if (dir == 1) {   // cube edge 3: v3 -> v0, direction -y, starting at (0,1,0)
+      const float t = edge_offset(vn, v0, iso);
+      x = (fX + (0.0f + t * 0.0f)) * sx + ox; y = (fY + (1.0f + t * -1.0f)) * sy + oy; z = (fZ + (0.0f + t * 0.0f)) * sz + oz;
+    } else {                 // cube edge 8: v0 -> v4, direction +z
+      const float t = edge_offset(v0, vn, iso);
+      x = (fX + (0.0f + t * 0.0f)) * sx + ox; y = (fY + (0.0f + t * 0.0f)) * sy + oy; z = (fZ + (0.0f + t * 1.0f)) * sz + oz;
+    }
+    }
+    verts[vid * 3 + 0] = x; verts[vid * 3 + 1] = y; verts[vid * 3 + 2] = z;
+  }
+}
+
+// Emit, step 3: one thread per triangle.
+__global__ __launch_bounds__(256) void mc_face_kernel(const float* __restrict__ sdf, Dim d, float iso, const uint64_t* __restrict__ planes,
+                                                       const uint32_t* __restrict__ voff64, const uint32_t* __restrict__ toff64,
+                                                       int64_t* __restrict__ faces) {
+  const int64_t total = (int64_t)d.NX * d.NY * d.NZ;
+  const int64_t F = toff64[(total + 63) >> 6];
+  const int64_t strideX = (int64_t)d.NY * d.NZ, strideY = d.NZ;
+  for (int64_t fid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; fid < F; fid += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = (uint64_t)faces[fid * 3];
+    const int64_t c = (int64_t)(key >> 3);
+    const int t = (int)(key & 7);
     float v[8];
     const int idx = cube_case(sdf, c, d.NY, d.NZ, iso, v);
-    const int own = owned_mask(v[0], v[1], v[3], v[4], iso);
-    if (own) {
-#pragma clang fp contract(off)   // keep (a*b)+c unfused: vertex coordinates are then bit-equal to the C oracle
-      uint32_t vid = voff[c];
-      const float fX = (float)i, fY = (float)j, fZ = (float)k;
-      if (own & 1) {   // cube edge 0: v0 -> v1, direction +x
-        const float t = edge_offset(v[0], v[1], iso);
-        verts[vid * 3 + 0] = (fX + (0.0f + t * 1.0f)) * sx + ox;
-        verts[vid * 3 + 1] = (fY + (0.0f + t * 0.0f)) * sy + oy;
-        verts[vid * 3 + 2] = (fZ + (0.0f + t * 0.0f)) * sz + oz;
-        ++vid;
-      }
-      if (own & 2) {   // cube edge 3: v3 -> v0, direction -y, starting at (0,1,0)
-        const float t = edge_offset(v[3], v[0], iso);
-        verts[vid * 3 + 0] = (fX + (0.0f + t * 0.0f)) * sx + ox;
-        verts[vid * 3 + 1] = (fY + (1.0f + t * -1.0f)) * sy + oy;
-        verts[vid * 3 + 2] = (fZ + (0.0f + t * 0.0f)) * sz + oz;
-        ++vid;
-      }
-      if (own & 4) {   // cube edge 8: v0 -> v4, direction +z
-        const float t = edge_offset(v[0], v[4], iso);
-        verts[vid * 3 + 0] = (fX + (0.0f + t * 0.0f)) * sx + ox;
-        verts[vid * 3 + 1] = (fY + (0.0f + t * 0.0f)) * sy + oy;
-        verts[vid * 3 + 2] = (fZ + (0.0f + t * 1.0f)) * sz + oz;
-      }
-    }
-    const int nt = dTriCount[idx];
-    if (nt == 0) continue;
-    const uint64_t word = dTri[idx];
-    int64_t* f = faces + (int64_t)toff[c] * 3;
-    for (int t = 0; t < nt; ++t) {
+    const uint64_t tri = dTri[idx];
+    int64_t out[3];
 #pragma unroll
-      for (int corner = 0; corner < 3; ++corner) {
-        const int e = (int)((word >> (4 * (3 * t + corner))) & 0xF);
-        const int bi = i + dEdgeBase[e][0], bj = j + dEdgeBase[e][1], bk = k + dEdgeBase[e][2], dir = dEdgeBase[e][3];
-        int64_t id = -1;
-        if (bi < d.NX - 1 && bj < d.NY - 1 && bk < d.NZ - 1) {   // the owner cell exists
-          const int64_t oc = (int64_t)bi * strideX + (int64_t)bj * strideY + bk;
-          const int m = owned_mask(sdf[oc], sdf[oc + strideX], sdf[oc + strideY], sdf[oc + 1], iso);
-          if (m & (1 << dir)) id = (int64_t)voff[oc] + __popc(m & ((1 << dir) - 1));
-        }
-        f[t * 3 + (2 - corner)] = id;   // reversed winding, CudaKernels.cu:503
-      }
+    for (int corner = 0; corner < 3; ++corner) {
+      const int e = (int)((tri >> (4 * (3 * t + corner))) & 0xF);
+      const int64_t oc = c + dEdgeBase[e][0] * strideX + dEdgeBase[e][1] * strideY + dEdgeBase[e][2];
+      // boundary cells have empty planes, so an edge whose owner cell does not exist resolves to -1 as in the reference
+      out[2 - corner] = vertex_id(planes, voff64, oc, dEdgeBase[e][3]);   // reversed winding, CudaKernels.cu:503
     }
+    faces[fid * 3 + 0] = out[0]; faces[fid * 3 + 1] = out[1]; faces[fid * 3 + 2] = out[2];
   }
 }
 
@@ -207,43 +309,57 @@ void exclusive_scan(uint32_t* data, int64_t n, uint32_t* sums, uint32_t* total_d
 
 extern "C" {
 
+// workspace: planes u64[6 G] | vs64 u32[G+1] | ts64 u32[G+1] | block sums u32[2*nblocks]   (G = ceil(n / 64) groups)
+struct McLayout { int64_t G, nblocks; };
+static McLayout mc_layout(int32_t nx, int32_t ny, int32_t nz) {
+  McLayout L;
+  const int64_t n = (int64_t)nx * ny * nz;
+  L.G = (n + 63) >> 6;
+  L.nblocks = sr_cdiv(L.G + 1, SCAN_ITEMS);
+  return L;
+}
+
 int64_t sr_mc_workspace_bytes(int32_t nx, int32_t ny, int32_t nz) {
   if (nx <= 0 || ny <= 0 || nz <= 0) return SR_EINVAL;
-  const int64_t n = (int64_t)nx * ny * nz;
-  const int64_t nblocks = sr_cdiv(n, SCAN_ITEMS);
-  return (2 * n + 2 * nblocks + 4) * (int64_t)sizeof(uint32_t);
+  const McLayout L = mc_layout(nx, ny, nz);
+  return L.G * MC_PLANES * (int64_t)sizeof(uint64_t) + (2 * (L.G + 1) + 2 * L.nblocks + 4) * (int64_t)sizeof(uint32_t);
 }
 
 // Pass 1: classify + scan.  counts_dev[0] = #vertices, counts_dev[1] = #faces (device, 2 x u32).
 int sr_mc_count(const float* sdf, int32_t nx, int32_t ny, int32_t nz, float iso, void* workspace, uint32_t* counts_dev, void* stream) {
   if (nx <= 0 || ny <= 0 || nz <= 0) return SR_EINVAL;
-  if (!sdf || !workspace || !counts_dev) return SR_EINVAL;
+  if (!sdf || !workspace || !counts_dev || ((uintptr_t)workspace & 7)) return SR_EINVAL;
   const int rc = ensure_tables();
   if (rc != SR_OK) return rc;
-  const int64_t n = (int64_t)nx * ny * nz;
-  const int64_t nblocks = sr_cdiv(n, SCAN_ITEMS);
-  uint32_t* vcnt = (uint32_t*)workspace;
-  uint32_t* tcnt = vcnt + n;
-  uint32_t* vsum = tcnt + n;
-  uint32_t* tsum = vsum + nblocks;
+  const McLayout L = mc_layout(nx, ny, nz);
+  uint64_t* planes = (uint64_t*)workspace;
+  uint32_t* vs64 = (uint32_t*)(planes + L.G * MC_PLANES);
+  uint32_t* ts64 = vs64 + (L.G + 1);
+  uint32_t* vsum = ts64 + (L.G + 1);
+  uint32_t* tsum = vsum + L.nblocks;
   hipStream_t st = (hipStream_t)stream;
   Dim d{nx, ny, nz};
-  hipLaunchKernelGGL(mc_classify_kernel, dim3(sr_stream_grid(n, 256)), dim3(256), 0, st, sdf, d, iso, vcnt, tcnt);
-  exclusive_scan(vcnt, n, vsum, counts_dev, st);
-  exclusive_scan(tcnt, n, tsum, counts_dev + 1, st);
+  hipLaunchKernelGGL(mc_classify_kernel, dim3(sr_stream_grid(sr_cdiv(L.G, MC_CHUNK) * 64, 256)), dim3(256), 0, st, sdf, d, iso, planes, vs64, ts64);
+  exclusive_scan(vs64, L.G + 1, vsum, counts_dev, st);
+  exclusive_scan(ts64, L.G + 1, tsum, counts_dev + 1, st);
   return sr_launch_status();
 }
 
 // Pass 2: emit into exactly-sized outputs (verts [V,3] f32 already scaled v*step+min, faces [F,3] i64).
 int sr_mc_emit(const float* sdf, int32_t nx, int32_t ny, int32_t nz, float iso, const void* workspace, float xstep, float ystep,
                float zstep, float xmin, float ymin, float zmin, float* verts, int64_t* faces, void* stream) {
-  if (nx <= 0 || ny <= 0 || nz <= 0 || !sdf || !workspace) return SR_EINVAL;
-  const int64_t n = (int64_t)nx * ny * nz;
-  const uint32_t* voff = (const uint32_t*)workspace;
-  const uint32_t* toff = voff + n;
+  if (nx <= 0 || ny <= 0 || nz <= 0 || !sdf || !workspace || !verts || !faces) return SR_EINVAL;
+  const McLayout L = mc_layout(nx, ny, nz);
+  const uint64_t* planes = (const uint64_t*)workspace;
+  const uint32_t* voff64 = (const uint32_t*)(planes + L.G * MC_PLANES);
+  const uint32_t* toff64 = voff64 + (L.G + 1);
+  hipStream_t st = (hipStream_t)stream;
   Dim d{nx, ny, nz};
-  hipLaunchKernelGGL(mc_emit_kernel, dim3(sr_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, sdf, d, iso, voff, toff, xstep,
-                     ystep, zstep, xmin, ymin, zmin, verts, faces);
+  hipLaunchKernelGGL(mc_tag_kernel, dim3(sr_stream_grid(L.G, 256)), dim3(256), 0, st, d, planes, voff64, toff64, (uint32_t*)verts, faces);
+  // V and F live on the device (off[G]); the per-output kernels bound their grid-stride loops by them
+  const int out_grid = sr_stream_grid(L.G * 8 < (int64_t)1 << 22 ? L.G * 8 : (int64_t)1 << 22, 256);
+  hipLaunchKernelGGL(mc_vertex_kernel, dim3(out_grid), dim3(256), 0, st, sdf, d, iso, voff64, xstep, ystep, zstep, xmin, ymin, zmin, verts);
+  hipLaunchKernelGGL(mc_face_kernel, dim3(out_grid), dim3(256), 0, st, sdf, d, iso, planes, voff64, toff64, faces);
   return sr_launch_status();
 }
 }
