@@ -7,15 +7,34 @@
 #include "sr_common.h"
 
 namespace {
+// (x, y, z, bc) of a flat voxel index, advanced through the grid-stride loop by carry arithmetic: the 64-bit divisions are
+// paid once per thread, not once per voxel.
+struct Walker {
+  int x, y, z; int64_t bc;
+  int dx, dy, dz; int64_t dbc;
+  int W, H, D;
+  __device__ Walker(int64_t start, int64_t stride, int W_, int H_, int D_) : W(W_), H(H_), D(D_) {
+    x = (int)(start % W); y = (int)((start / W) % H); z = (int)((start / ((int64_t)W * H)) % D); bc = start / ((int64_t)W * H * D);
+    dx = (int)(stride % W); dy = (int)((stride / W) % H); dz = (int)((stride / ((int64_t)W * H)) % D); dbc = stride / ((int64_t)W * H * D);
+  }
+  __device__ __forceinline__ void advance() {
+    x += dx; if (x >= W) { x -= W; ++y; }
+    y += dy; if (y >= H) { y -= H; ++z; }
+    z += dz; if (z >= D) { z -= D; ++bc; }
+    bc += dbc;
+  }
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void interp2x_fwd_kernel(const T* __restrict__ in, int64_t BC, int d, int h, int w, float balance,
                                                             T* __restrict__ out, uint8_t* __restrict__ bnd) {
   const int D = 2 * d - 1, H = 2 * h - 1, W = 2 * w - 1;
   const int64_t total = BC * D * H * W;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)((i / ((int64_t)W * H)) % D);
-    const int64_t bc = i / ((int64_t)D * H * W);
-    const T* src = in + bc * d * h * w;
+  const int64_t start = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  Walker p(start, stride, W, H, D);
+  for (int64_t i = start; i < total; i += stride, p.advance()) {
+    const int x = p.x, y = p.y, z = p.z;
+    const T* src = in + p.bc * d * h * w;
     const bool ox = x & 1, oy = y & 1, oz = z & 1;
     const int x0 = ox ? (x - 1) / 2 : x / 2, x1 = ox ? (x + 1) / 2 : x / 2;
     const int y0 = oy ? (y - 1) / 2 : y / 2, y1 = oy ? (y + 1) / 2 : y / 2;
@@ -41,7 +60,7 @@ __global__ __launch_bounds__(256) void interp2x_fwd_kernel(const T* __restrict__
     bool disagree = false;
     const bool f0 = v[0] > (T)balance;
     for (int k = 1; k < n; ++k) { s += v[k]; disagree |= ((v[k] > (T)balance) != f0); }
-    out[i] = n == 1 ? s : (T)((double)s / (double)n);
+    out[i] = s * (n == 1 ? T(1) : n == 2 ? T(0.5) : n == 4 ? T(0.25) : T(0.125));   // == (T)((double)s / n): n is a power of two
     bnd[i] = disagree ? 1 : 0;
   }
 }
@@ -50,15 +69,17 @@ template <typename T>
 __global__ __launch_bounds__(256) void interp2x_bwd_kernel(const T* __restrict__ go, int64_t BC, int d, int h, int w, T* __restrict__ gi) {
   const int D = 2 * d - 1, H = 2 * h - 1, W = 2 * w - 1;
   const int64_t total = BC * d * h * w;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int x = (int)(i % w), y = (int)((i / w) % h), z = (int)((i / ((int64_t)w * h)) % d);
-    const int64_t bc = i / ((int64_t)d * h * w);
-    const T* src = go + bc * D * H * W;
+  const int64_t start = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  Walker p(start, stride, w, h, d);
+  for (int64_t i = start; i < total; i += stride, p.advance()) {
+    const int x = p.x, y = p.y, z = p.z;
+    const T* src = go + p.bc * D * H * W;
     auto at = [&](int zz, int yy, int xx) { return src[((int64_t)zz * H + yy) * W + xx]; };
     const bool xm = x > 0, xp = x < w - 1, ym = y > 0, yp = y < h - 1, zm = z > 0, zp = z < d - 1;
     const int X = 2 * x, Y = 2 * y, Z = 2 * z;
     T g = at(Z, Y, X);
-    auto add = [&](bool ok, int zz, int yy, int xx, double div) { if (ok) g = (T)((double)g + (double)at(zz, yy, xx) / div); };
+    // (T)((double)g + (double)v / div): v / div is exact (div a power of two), one rounding from the double sum
+    auto add = [&](bool ok, int zz, int yy, int xx, double div) { if (ok) g = (T)((double)g + (double)at(zz, yy, xx) * (1.0 / div)); };
     // the reference's accumulation order (:180-236): 6 edges, 12 faces (xy, xz, yz), 8 corners
     add(xm, Z, Y, X - 1, 2.0); add(xp, Z, Y, X + 1, 2.0); add(ym, Z, Y - 1, X, 2.0); add(yp, Z, Y + 1, X, 2.0);
     add(zm, Z - 1, Y, X, 2.0); add(zp, Z + 1, Y, X, 2.0);

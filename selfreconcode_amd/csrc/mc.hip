@@ -63,9 +63,16 @@ __global__ __launch_bounds__(256) void mc_classify_kernel(const float* __restric
   const int64_t G = (total + 63) >> 6;
   const int64_t sx = (int64_t)d.NY * d.NZ, sy = d.NZ;
   const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   if (blockIdx.x == 0 && threadIdx.x == 0) { vs64[G] = 0; ts64[G] = 0; }   // scan sentinel: off[G] = total
-  for (int64_t g0 = wave * MC_CHUNK; g0 < G; g0 += nwaves * MC_CHUNK) {
+  // XCD-aware order (gridDim.x is a multiple of 8, block b runs on XCD b % 8): each XCD sweeps its own contiguous eighth of
+  // the volume, so the rows j+1 and planes i+1 a chunk shares with its neighbours are found in that XCD's L2
+  const int64_t nchunks = (G + MC_CHUNK - 1) / MC_CHUNK;
+  const int64_t per_xcd = (nchunks + 7) / 8;
+  const int xcd = blockIdx.x & 7;
+  const int64_t lwave = (int64_t)(blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6), lwaves = (int64_t)(gridDim.x >> 3) * (blockDim.x >> 6);
+  const int64_t chunk_end = (xcd + 1) * per_xcd < nchunks ? (xcd + 1) * per_xcd : nchunks;
+  for (int64_t chunk = xcd * per_xcd + lwave; chunk < chunk_end; chunk += lwaves) {
+    const int64_t g0 = chunk * MC_CHUNK;
     int64_t c = (g0 << 6) + lane;
     const int64_t row = c / d.NZ;
     int k = (int)(c - row * d.NZ), i = (int)(row / d.NY);
@@ -339,7 +346,7 @@ int sr_mc_count(const float* sdf, int32_t nx, int32_t ny, int32_t nz, float iso,
   uint32_t* tsum = vsum + L.nblocks;
   hipStream_t st = (hipStream_t)stream;
   Dim d{nx, ny, nz};
-  hipLaunchKernelGGL(mc_classify_kernel, dim3(sr_stream_grid(sr_cdiv(L.G, MC_CHUNK) * 64, 256)), dim3(256), 0, st, sdf, d, iso, planes, vs64, ts64);
+  hipLaunchKernelGGL(mc_classify_kernel, dim3((sr_stream_grid(sr_cdiv(L.G, MC_CHUNK) * 64, 256) + 7) & ~7), dim3(256), 0, st, sdf, d, iso, planes, vs64, ts64);
   exclusive_scan(vs64, L.G + 1, vsum, counts_dev, st);
   exclusive_scan(ts64, L.G + 1, tsum, counts_dev + 1, st);
   return sr_launch_status();

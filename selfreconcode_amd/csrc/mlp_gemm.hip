@@ -13,8 +13,9 @@
 //
 // Tiling: 128x128x32 per 256-thread workgroup (2x2 waves of 64x64 = 2x2 MFMA blocks, 64
 // accumulator VGPRs), operands staged through LDS in [row][32+4] images -- a 144-byte row pitch
-// makes the ds_read_b128 fragment reads bank-conflict free -- double buffered, with the next
-// tile's global loads issued before the MFMA block of the current one.
+// makes the ds_read_b128 fragment reads bank-conflict free -- double buffered in LDS and in
+// registers: tile t+2 is in flight from global memory while tile t+1 moves registers -> LDS and
+// tile t feeds the MFMAs; the one barrier per tile sits in the middle of the MFMA stream.
 #include "sr_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -56,38 +57,46 @@ struct Cfg {
   static constexpr int kLdsFloats = 2 * (BM + BN) * LDSP;
 };
 
-// Loads a [ROWS x 32] tile (rows r0.., k from k0) as float4 per thread with zero fill outside
-// [0,R) x [0,K).  Requires ld % 4 == 0 and a 16-byte aligned base.
+// Operand tiles move global -> registers -> LDS as one float4 per thread and slot.  Everything is branch-free so the tile loop is
+// ONE basic block the scheduler can interleave with the MFMA stream: rows outside [0,R) are clamped to a valid row (their
+// products land in accumulator rows / columns the epilogue never stores), and the K tail is zeroed with selects.
 template <int ROWS, int NLOADS, int THREADS>
-__device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t ld, int R, int K, int r0, int k0,
-                                          f32x4 (&reg)[NLOADS]) {
+struct TileLoader {
+  const float* p[NLOADS];   // row base + kq*4 of each slot (row clamped)
+  int kq4;                  // this thread's k offset inside a tile (same for all slots: THREADS % 8 == 0)
+  int K, kmax;              // logical K and the last float4 start that stays inside the padded row
+  __device__ __forceinline__ TileLoader(const float* __restrict__ P, int64_t ld, int R, int K_, int r0) : K(K_) {
+    kq4 = (threadIdx.x & 7) * 4;
+    kmax = ((K_ + 3) & ~3) - 4;
 #pragma unroll
-  for (int j = 0; j < NLOADS; ++j) {
-    const int idx = threadIdx.x + j * THREADS;
-    const int row = idx >> 3, kq = idx & 7;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    const int gr = r0 + row, gk = k0 + kq * 4;
-    if (idx < ROWS * 8 && gr < R && gk < K) {
-      v = *reinterpret_cast<const f32x4*>(P + (int64_t)gr * ld + gk);
-      if (gk + 3 >= K) {  // ragged K tail inside this float4
-        if (gk + 1 >= K) v.y = 0.f;
-        if (gk + 2 >= K) v.z = 0.f;
-        if (gk + 3 >= K) v.w = 0.f;
-      }
+    for (int j = 0; j < NLOADS; ++j) {
+      int row = (threadIdx.x + j * THREADS) >> 3;
+      if (row >= ROWS) row = ROWS - 1;
+      int gr = r0 + row;
+      if (gr >= R) gr = R - 1;
+      p[j] = P + (int64_t)gr * ld;
     }
-    reg[j] = v;
   }
-}
-
-template <int ROWS, int NLOADS, int THREADS>
-__device__ __forceinline__ void store_tile(float* __restrict__ lds, const f32x4 (&reg)[NLOADS]) {
+  // raw loads; the K tail is masked when the registers are written to LDS (a select right after the load would make the
+  // wave wait for the data in the same iteration)
+  __device__ __forceinline__ void load(int k0, f32x4 (&reg)[NLOADS]) const {
+    const int gk = k0 + kq4;
+    const int gkc = gk < kmax ? gk : kmax;
 #pragma unroll
-  for (int j = 0; j < NLOADS; ++j) {
-    const int idx = threadIdx.x + j * THREADS;
-    const int row = idx >> 3, kq = idx & 7;
-    if (idx < ROWS * 8) *reinterpret_cast<f32x4*>(lds + row * LDSP + kq * 4) = reg[j];
+    for (int j = 0; j < NLOADS; ++j) reg[j] = *reinterpret_cast<const f32x4*>(p[j] + gkc);
   }
-}
+  __device__ __forceinline__ void store(float* __restrict__ lds, int k0, const f32x4 (&reg)[NLOADS]) const {
+    const int nvalid = K - (k0 + kq4);      // floats of this float4 inside [0,K): >= 4 keeps all, <= 0 keeps none
+#pragma unroll
+    for (int j = 0; j < NLOADS; ++j) {
+      const int idx = threadIdx.x + j * THREADS;
+      const int row = idx >> 3;
+      f32x4 v = reg[j];
+      v.x = nvalid > 0 ? v.x : 0.f; v.y = nvalid > 1 ? v.y : 0.f; v.z = nvalid > 2 ? v.z : 0.f; v.w = nvalid > 3 ? v.w : 0.f;
+      if (ROWS * 8 % THREADS == 0 || row < ROWS) *reinterpret_cast<f32x4*>(lds + row * LDSP + kq4) = v;
+    }
+  }
+};
 
 // Epilogue for one wave: every lane holds, per 32x32 block, 4 quads of 4 consecutive rows (one column).
 // G rows form one sample (primal + G-1 tangents); all per-sample maths is in-register.
@@ -220,42 +229,67 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(sr_gemm_args g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  f32x4 ra[C_::kALoads], rb[C_::kBLoads];
+  // Software-pipelined tile loop, one barrier per tile placed in the MIDDLE of the MFMA stream:
+  //   first half : LDS <- registers (tile t+1), issue the global loads of tile t+2, read the kk=2,3 fragments of tile t,
+  //                32 MFMAs on the kk=0,1 fragments fetched during the previous iteration
+  //   barrier    : tile t+1 is now visible AND every wave has finished reading tile t's buffer
+  //   second half: read the kk=0,1 fragments of tile t+1, 32 MFMAs on the kk=2,3 fragments
+  // so the wave always holds a half tile of fragments in registers when it meets the barrier, and global loads have a whole
+  // tile of MFMA time to land.  Loads past the last tile are clamped re-reads whose data is never used.
+  const TileLoader<C_::BM, C_::kALoads, C_::kThreads> la(g.A, g.lda, g.M, g.K, m0);
+  const TileLoader<C_::BN, C_::kBLoads, C_::kThreads> lb(g.B, g.ldb, g.N, g.K, n0);
+  f32x4 ra0[C_::kALoads], rb0[C_::kBLoads], ra1[C_::kALoads], rb1[C_::kBLoads];   // two register stages: tile t+1 (to LDS) and t+2 (in flight)
   const int nk = (g.K + BK - 1) / BK;
-  load_tile<C_::BM, C_::kALoads, C_::kThreads>(g.A, g.lda, g.M, g.K, m0, 0, ra);
-  load_tile<C_::BN, C_::kBLoads, C_::kThreads>(g.B, g.ldb, g.N, g.K, n0, 0, rb);
-  store_tile<C_::BM, C_::kALoads, C_::kThreads>(As(0), ra);
-  store_tile<C_::BN, C_::kBLoads, C_::kThreads>(Bs(0), rb);
+  la.load(0, ra0); lb.load(0, rb0);
+  la.load(BK, ra1); lb.load(BK, rb1);
+  la.store(As(0), 0, ra0); lb.store(Bs(0), 0, rb0);
   __syncthreads();
 
-  for (int t = 0; t < nk; ++t) {
+  const int a_off = (wm * TM * 32 + li) * LDSP + kh * 4, b_off = (wn * TN * 32 + li) * LDSP + kh * 4;
+  f32x4 fa0[2][TM], fb0[2][TN], fa1[2][TM], fb1[2][TN];   // fragments of kk = 0,1 and kk = 2,3
+  auto read_frags = [&](const float* abuf, const float* bbuf, int kk0, f32x4 (&fa)[2][TM], f32x4 (&fb)[2][TN]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a) fa[h][a] = *reinterpret_cast<const f32x4*>(abuf + a_off + a * 32 * LDSP + (kk0 + h) * 8);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) fb[h][b] = *reinterpret_cast<const f32x4*>(bbuf + b_off + b * 32 * LDSP + (kk0 + h) * 8);
+    }
+  };
+  auto mfma_kk = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {   // one kk = 8 k-values = 4 x TM x TN MFMAs
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][e], fb[b][e], acc[a][b], 0, 0, 0);
+  };
+  read_frags(As(0), Bs(0), 0, fa0, fb0);
+
+  // one tile step: `in` receives tile t+2 from global memory (issued first, so it has the whole step to land), `out` holds
+  // tile t+1 (loaded during the previous step) and goes to the other LDS buffer
+  auto step = [&](int t, f32x4 (&ain)[C_::kALoads], f32x4 (&bin)[C_::kBLoads], const f32x4 (&aout)[C_::kALoads],
+                  const f32x4 (&bout)[C_::kBLoads]) {
     const int cur = t & 1;
-    if (t + 1 < nk) {
-      load_tile<C_::BM, C_::kALoads, C_::kThreads>(g.A, g.lda, g.M, g.K, m0, (t + 1) * BK, ra);
-      load_tile<C_::BN, C_::kBLoads, C_::kThreads>(g.B, g.ldb, g.N, g.K, n0, (t + 1) * BK, rb);
-    }
-    const float* a_base = As(cur) + (wm * TM * 32 + li) * LDSP + kh * 4;
-    const float* b_base = Bs(cur) + (wn * TN * 32 + li) * LDSP + kh * 4;
-#pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      f32x4 fa[TM], fb[TN];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const f32x4*>(a_base + a * 32 * LDSP + kk * 8);
-#pragma unroll
-      for (int b = 0; b < TN; ++b) fb[b] = *reinterpret_cast<const f32x4*>(b_base + b * 32 * LDSP + kk * 8);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][e], fb[b][e], acc[a][b], 0, 0, 0);
-    }
-    if (t + 1 < nk) {
-      store_tile<C_::BM, C_::kALoads, C_::kThreads>(As(cur ^ 1), ra);
-      store_tile<C_::BN, C_::kBLoads, C_::kThreads>(Bs(cur ^ 1), rb);
-    }
+    la.load((t + 2) * BK, ain); lb.load((t + 2) * BK, bin);
+    __builtin_amdgcn_sched_barrier(0);
+    la.store(As(cur ^ 1), (t + 1) * BK, aout); lb.store(Bs(cur ^ 1), (t + 1) * BK, bout);
+    read_frags(As(cur), Bs(cur), 2, fa1, fb1);
+    mfma_kk(fa0[0], fb0[0]);
+    __builtin_amdgcn_sched_barrier(0);   // keep a quarter tile of MFMAs between the LDS traffic above and the barrier below
+    mfma_kk(fa0[1], fb0[1]);
+    __builtin_amdgcn_sched_barrier(0);   // ... and issue it before waiting: the LDS traffic has drained by the time the wave reaches the barrier
     __syncthreads();
+    read_frags(As(cur ^ 1), Bs(cur ^ 1), 0, fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);   // next tile's first fragments are requested straight after the barrier, half a tile before use
+    mfma_kk(fa1[0], fb1[0]);
+    mfma_kk(fa1[1], fb1[1]);
+  };
+  for (int t = 0; t < nk; t += 2) {
+    step(t, ra0, rb0, ra1, rb1);
+    if (t + 1 < nk) step(t + 1, ra1, rb1, ra0, rb0);
   }
+  __syncthreads();   // the epilogue reuses the operand buffers
 
   // ---------------------------------------------------------------- epilogue
   float* stage = smem + wave * (TM * 32 * (TN * 32 + 4));   // the operand buffers are free after the last barrier
