@@ -55,6 +55,7 @@ class SrError(RuntimeError):
 
 _CODES = {-1: "SR_EINVAL (bad argument)", -2: "SR_ELAUNCH (kernel launch failed)", -3: "SR_ENOSPC (workspace too small)"}
 
+LIB = os.environ.get("SELFRECON_HIP_LIB", LIB)   # tuning hook: point at an experimental build of the same ABI
 if not os.path.isfile(LIB):
     raise ImportError(f"{LIB} not found: run `python -m selfreconcode_amd.build` (hipcc --offload-arch=gfx950). "
                       "There is no CPU fallback for the HIP hot path.")

@@ -13,10 +13,11 @@
 //
 // Tiling: 128x128x32 per 256-thread workgroup (2x2 waves of 64x64 = 2x2 MFMA blocks, 64
 // accumulator VGPRs), operands staged through LDS in [row][32+4] images -- a 144-byte row pitch
-// makes the ds_read_b128 fragment reads bank-conflict free -- double buffered in LDS and in
-// registers: tile t+2 is in flight from global memory while tile t+1 moves registers -> LDS and
-// tile t feeds the MFMAs; the one barrier per tile sits in the middle of the MFMA stream.
+// makes the ds_read_b128 fragment reads bank-conflict free -- double buffered in LDS plus one
+// register stage: tile t+2 is in flight from global memory while tile t+1 sits in the other LDS
+// buffer and tile t feeds the MFMAs; the one barrier per tile sits in the middle of the MFMA stream.
 #include "sr_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -54,7 +55,9 @@ struct Cfg {
   static constexpr int BN = WN * TN * 32;
   static constexpr int kALoads = BM * (BK / 4) / kThreads;  // float4 per thread per tile
   static constexpr int kBLoads = (BN * (BK / 4) + kThreads - 1) / kThreads;
-  static constexpr int kLdsFloats = 2 * (BM + BN) * LDSP;
+  static constexpr int kOperandFloats = 2 * (BM + BN) * LDSP;            // two LDS buffers of A and B tiles
+  static constexpr int kStageFloats = kWaves * TM * 32 * (TN * 32 + 4);  // epilogue staging image, one per wave
+  static constexpr int kLdsFloats = kOperandFloats > kStageFloats ? kOperandFloats : kStageFloats;
 };
 
 // Operand tiles move global -> registers -> LDS as one float4 per thread and slot.  Everything is branch-free so the tile loop is
@@ -198,7 +201,7 @@ __device__ __forceinline__ void epilogue(const sr_gemm_args& g, f32x16 (&acc)[TM
 // ------------------------------------------------------------------------------------------------
 // C = epilogue(A[M,K] * B[N,K]^T)
 template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(sr_gemm_args g) {
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_kernel(sr_gemm_args g) {
   using C_ = Cfg<WM, WN, TM, TN>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   auto As = [&](int buf) -> float* { return smem + buf * (C_::BM * LDSP); };
@@ -229,22 +232,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(sr_gemm_args g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // Software-pipelined tile loop, one barrier per tile placed in the MIDDLE of the MFMA stream:
-  //   first half : LDS <- registers (tile t+1), issue the global loads of tile t+2, read the kk=2,3 fragments of tile t,
-  //                32 MFMAs on the kk=0,1 fragments fetched during the previous iteration
-  //   barrier    : tile t+1 is now visible AND every wave has finished reading tile t's buffer
-  //   second half: read the kk=0,1 fragments of tile t+1, 32 MFMAs on the kk=2,3 fragments
-  // so the wave always holds a half tile of fragments in registers when it meets the barrier, and global loads have a whole
-  // tile of MFMA time to land.  Loads past the last tile are clamped re-reads whose data is never used.
+  // Software-pipelined tile loop with one barrier per tile placed in the MIDDLE of the MFMA stream: the wave holds half a
+  // tile of fragments in registers when it meets the barrier.  Loads past the last tile are clamped re-reads, never used.
   const TileLoader<C_::BM, C_::kALoads, C_::kThreads> la(g.A, g.lda, g.M, g.K, m0);
   const TileLoader<C_::BN, C_::kBLoads, C_::kThreads> lb(g.B, g.ldb, g.N, g.K, n0);
-  f32x4 ra0[C_::kALoads], rb0[C_::kBLoads], ra1[C_::kALoads], rb1[C_::kBLoads];   // two register stages: tile t+1 (to LDS) and t+2 (in flight)
   const int nk = (g.K + BK - 1) / BK;
-  la.load(0, ra0); lb.load(0, rb0);
-  la.load(BK, ra1); lb.load(BK, rb1);
-  la.store(As(0), 0, ra0); lb.store(Bs(0), 0, rb0);
-  __syncthreads();
-
   const int a_off = (wm * TM * 32 + li) * LDSP + kh * 4, b_off = (wn * TN * 32 + li) * LDSP + kh * 4;
   f32x4 fa0[2][TM], fb0[2][TN], fa1[2][TM], fb1[2][TN];   // fragments of kk = 0,1 and kk = 2,3
   auto read_frags = [&](const float* abuf, const float* bbuf, int kk0, f32x4 (&fa)[2][TM], f32x4 (&fb)[2][TN]) {
@@ -264,26 +256,50 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(sr_gemm_args g) {
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][e], fb[b][e], acc[a][b], 0, 0, 0);
   };
-  read_frags(As(0), Bs(0), 0, fa0, fb0);
+  constexpr int kMem = C_::kALoads + C_::kBLoads;          // float4 slots per thread and tile
 
-  // one tile step: `in` receives tile t+2 from global memory (issued first, so it has the whole step to land), `out` holds
-  // tile t+1 (loaded during the previous step) and goes to the other LDS buffer
+  // Two register stages: tile t+2 is requested from global memory at the top of step t and written to LDS at the top of step
+  // t+1, so a load has a whole step to land.  Per step the wave issues, in this order and each slotted between two MFMAs
+  // (sched_group_barrier): the refill loads, the LDS stores of tile t+1, the kk=2,3 fragment reads of tile t; then the one
+  // barrier of the step, the kk=0,1 fragment reads of tile t+1 and the second half of the MFMAs.  Measured with s_memtime
+  // stamps (profiles/r01_summary.md): with the memory operations in their own phase the wave spent 1000-1500 clk per
+  // 4096-clk step with an idle MFMA pipe.
+  f32x4 ra0[C_::kALoads], rb0[C_::kBLoads], ra1[C_::kALoads], rb1[C_::kBLoads];
+  la.load(0, ra0); lb.load(0, rb0);
+  la.load(BK, ra1); lb.load(BK, rb1);
+  la.store(As(0), 0, ra0); lb.store(Bs(0), 0, rb0);
+  __syncthreads();
+  read_frags(As(0), Bs(0), 0, fa0, fb0);
   auto step = [&](int t, f32x4 (&ain)[C_::kALoads], f32x4 (&bin)[C_::kBLoads], const f32x4 (&aout)[C_::kALoads],
                   const f32x4 (&bout)[C_::kBLoads]) {
     const int cur = t & 1;
     la.load((t + 2) * BK, ain); lb.load((t + 2) * BK, bin);
-    __builtin_amdgcn_sched_barrier(0);
     la.store(As(cur ^ 1), (t + 1) * BK, aout); lb.store(Bs(cur ^ 1), (t + 1) * BK, bout);
     read_frags(As(cur), Bs(cur), 2, fa1, fb1);
     mfma_kk(fa0[0], fb0[0]);
-    __builtin_amdgcn_sched_barrier(0);   // keep a quarter tile of MFMAs between the LDS traffic above and the barrier below
     mfma_kk(fa0[1], fb0[1]);
-    __builtin_amdgcn_sched_barrier(0);   // ... and issue it before waiting: the LDS traffic has drained by the time the wave reaches the barrier
+#pragma unroll
+    for (int i = 0; i < kMem; ++i) {        // global loads first (one per MFMA), then the LDS stores, then the fragment reads
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < kMem; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * (TM + TN); ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     read_frags(As(cur ^ 1), Bs(cur ^ 1), 0, fa0, fb0);
-    __builtin_amdgcn_sched_barrier(0);   // next tile's first fragments are requested straight after the barrier, half a tile before use
+    __builtin_amdgcn_sched_barrier(0);
     mfma_kk(fa1[0], fb1[0]);
     mfma_kk(fa1[1], fb1[1]);
+    __builtin_amdgcn_sched_barrier(0);
   };
   for (int t = 0; t < nk; t += 2) {
     step(t, ra0, rb0, ra1, rb1);
@@ -476,7 +492,6 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Z
 }  // namespace
 
 extern "C" {
-
 int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
   if (!a || a->M < 0 || a->N <= 0 || a->K <= 0) return SR_EINVAL;
   if (a->M == 0) return SR_OK;
@@ -499,25 +514,34 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
     const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));
     hipLaunchKernelGGL((gemm_nt_kernel<4, 1, 2, 1>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), (hipStream_t)stream, g);
   } else {
+    // a round = every CU holding `per_cu` tiles that share its MFMA pipes; its duration ~ per_cu * bm * bn / eff
     auto cost = [&](int bm, int bn, int per_cu, double eff) {
       const double wgs = (double)sr_cdiv(g.M, bm) * (double)sr_cdiv(ncols, bn);
       const double rounds = (double)sr_cdiv((int64_t)wgs, 256 * per_cu);
-      return rounds * bm * bn / eff;
+      return rounds * per_cu * bm * bn / eff;
     };
-    const double c128 = cost(128, 128, 2, 1.0), c64x128 = cost(64, 128, 2, 0.92), c64 = cost(64, 64, 4, 0.75);
-    if (c64 < c128 && c64 < c64x128) {
-      using C_ = Cfg<2, 2, 1, 1>;
-      const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));
-      hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 1, 1>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), (hipStream_t)stream, g);
-    } else if (c64x128 < c128) {
-      using C_ = Cfg<2, 2, 1, 2>;
-      const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));
-      hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 1, 2>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), (hipStream_t)stream, g);
-    } else {
-      using C_ = Cfg<2, 2, 2, 2>;
-      const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));
-      hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 2, 2>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), (hipStream_t)stream, g);
+    static const int forced = getenv("SR_NT_CFG") ? atoi(getenv("SR_NT_CFG")) : 0;   // tuning switch
+    int pick = forced;
+    if (!pick) {
+      const double c[3] = {cost(64, 64, 4, 0.92), cost(64, 128, 2, 0.94), cost(128, 128, 2, 1.0)};   // eff: measured large-M rates / 118 TF
+      pick = 1;
+      for (int i = 1; i < 3; ++i) if (c[i] < c[pick - 1]) pick = i + 1;
     }
+#define SR_NT_LAUNCH(WM, WN, TM, TN)                                                                                        \
+  do {                                                                                                                      \
+    using C_ = Cfg<WM, WN, TM, TN>;                                                                                         \
+    const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));                                                   \
+    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float),     \
+                       (hipStream_t)stream, g);                                                                             \
+  } while (0)
+    switch (pick) {
+      case 1: SR_NT_LAUNCH(2, 2, 1, 1); break;
+      case 2: SR_NT_LAUNCH(2, 2, 1, 2); break;
+      case 3: SR_NT_LAUNCH(2, 2, 2, 2); break;
+      case 4: SR_NT_LAUNCH(4, 2, 2, 2); break;
+      default: SR_NT_LAUNCH(2, 4, 2, 2); break;
+    }
+#undef SR_NT_LAUNCH
   }
   return sr_launch_status();
 }
