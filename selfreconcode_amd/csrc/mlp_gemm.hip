@@ -318,12 +318,14 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
 
 // ------------------------------------------------------------------------------------------------
 // dW[N,K] = sum_r Z[r,N]^T A[r,K]   (split over r into `splits` slabs, reduced below)
-constexpr int TBR = 16;          // rows (reduction) per tile step
-constexpr int TLD = 128 + 4;     // LDS pitch for the [32][128] images
+constexpr int TBR = 32;          // rows (reduction) per tile step
+constexpr int TLD = 128 + 4;     // LDS pitch for the [TBR][128] images
+constexpr int TN_LDS_FLOATS = 4 * TBR * TLD;   // Z and A images, double buffered (67.6 KB, dynamic)
 
-__global__ __launch_bounds__(256) void gemm_tn_kernel(sr_gemm_tn_args g, int rows_per_split) {
-  __shared__ __attribute__((aligned(16))) float Zs[2][TBR * TLD];
-  __shared__ __attribute__((aligned(16))) float Xs[2][TBR * TLD];
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_tn_kernel(sr_gemm_tn_args g, int rows_per_split) {
+  extern __shared__ __attribute__((aligned(16))) float tn_smem[];
+  auto Zs = [&](int buf) -> float* { return tn_smem + buf * (TBR * TLD); };
+  auto Xs = [&](int buf) -> float* { return tn_smem + (2 + buf) * (TBR * TLD); };
   const int tiles_k = (g.K + 127) / 128;
   const int tiles_n = (g.N + 127) / 128;
   // XCD-aware order: workgroup b runs on XCD b % 8 with a private L2.  The tiles of one row-slice (split) all read the
@@ -346,92 +348,123 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(sr_gemm_tn_args g, int row
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // tile [TBR rows][128 cols] of Z and of A per step: TBR*32 float4 each, TLOADS per thread
+  // A step moves a [TBR rows][128 cols] tile of Z and of A: TBR*32 float4 each, TLOADS per thread and operand.  Like the NT
+  // loop it is branch-free (one basic block): row addresses are clamped into the slice, rows past its end are zeroed with
+  // selects when the registers go to LDS (they are the reduction dimension and must contribute nothing), and columns past
+  // N / K are clamped re-reads whose products land in rows / columns of dW that are never stored.
   constexpr int TLOADS = TBR * 32 / 256;
+  const int cq4 = (threadIdx.x & 31) * 4, lrow = threadIdx.x >> 5;    // this thread's column quad and first row inside a tile
+  const int zmax = ((g.N + 3) & ~3) - 4, xmax = ((g.K + 3) & ~3) - 4;
+  const float* zcol = g.Z + (n0 + cq4 < zmax ? n0 + cq4 : zmax);
+  const float* xcol = g.A + (k0 + cq4 < xmax ? k0 + cq4 : xmax);
   f32x4 rz[TLOADS], rx[TLOADS];
   auto load = [&](int r0) {
 #pragma unroll
     for (int j = 0; j < TLOADS; ++j) {
-      const int idx = threadIdx.x + j * 256;
-      const int row = idx >> 5, cq = idx & 31;
-      const int gr = r0 + row;
-      f32x4 z = {0.f, 0.f, 0.f, 0.f}, x = {0.f, 0.f, 0.f, 0.f};
-      if (gr < r_end) {
-        const int cn = n0 + cq * 4, ck = k0 + cq * 4;
-        if (cn < g.N) {
-          z = *reinterpret_cast<const f32x4*>(g.Z + (int64_t)gr * g.ldz + cn);
-          if (cn + 1 >= g.N) z.y = 0.f;
-          if (cn + 2 >= g.N) z.z = 0.f;
-          if (cn + 3 >= g.N) z.w = 0.f;
-        }
-        if (ck < g.K) {
-          x = *reinterpret_cast<const f32x4*>(g.A + (int64_t)gr * g.lda + ck);
-          if (ck + 1 >= g.K) x.y = 0.f;
-          if (ck + 2 >= g.K) x.z = 0.f;
-          if (ck + 3 >= g.K) x.w = 0.f;
-        }
-      }
-      rz[j] = z; rx[j] = x;
+      int gr = r0 + lrow + j * 8;
+      gr = gr < r_end ? gr : r_end - 1;
+      rz[j] = *reinterpret_cast<const f32x4*>(zcol + (int64_t)gr * g.ldz);
+      rx[j] = *reinterpret_cast<const f32x4*>(xcol + (int64_t)gr * g.lda);
     }
   };
-  auto store = [&](int buf) {
+  auto store = [&](int buf, int r0) {
+    float* zs = Zs(buf);
+    float* xs = Xs(buf);
 #pragma unroll
     for (int j = 0; j < TLOADS; ++j) {
-      const int idx = threadIdx.x + j * 256;
-      const int row = idx >> 5, cq = idx & 31;
-      *reinterpret_cast<f32x4*>(&Zs[buf][row * TLD + cq * 4]) = rz[j];
-      *reinterpret_cast<f32x4*>(&Xs[buf][row * TLD + cq * 4]) = rx[j];
+      const int row = lrow + j * 8;
+      const bool ok = r0 + row < r_end;
+      f32x4 z = rz[j], x = rx[j];
+      z.x = ok ? z.x : 0.f; z.y = ok ? z.y : 0.f; z.z = ok ? z.z : 0.f; z.w = ok ? z.w : 0.f;
+      x.x = ok ? x.x : 0.f; x.y = ok ? x.y : 0.f; x.z = ok ? x.z : 0.f; x.w = ok ? x.w : 0.f;
+      *reinterpret_cast<f32x4*>(zs + row * TLD + cq4) = z;
+      *reinterpret_cast<f32x4*>(xs + row * TLD + cq4) = x;
     }
   };
 
-  // bias gradient rides along: workgroups of the first K-tile also sum their Z tile over the primal rows
+  // fragments of 8 k-steps (16 rows): one dword per k-step and 32-wide block
+  constexpr int HS = TBR / 4;   // k-steps per half tile
+  float z0a[HS], z1a[HS], x0a[HS], x1a[HS], z0b[HS], z1b[HS], x0b[HS], x1b[HS];
+  const int zoff = kh * TLD + wm * 64 + li, xoff = kh * TLD + wn * 64 + li;
+  auto read_half = [&](int buf, int half, float (&z0)[HS], float (&z1)[HS], float (&x0)[HS], float (&x1)[HS]) {
+    const float* zb = Zs(buf) + zoff + half * HS * 2 * TLD;
+    const float* xb = Xs(buf) + xoff + half * HS * 2 * TLD;
+#pragma unroll
+    for (int e = 0; e < HS; ++e) { z0[e] = zb[2 * e * TLD]; z1[e] = zb[2 * e * TLD + 32]; x0[e] = xb[2 * e * TLD]; x1[e] = xb[2 * e * TLD + 32]; }
+  };
+  auto mfma_half = [&](const float (&z0)[HS], const float (&z1)[HS], const float (&x0)[HS], const float (&x1)[HS]) {
+#pragma unroll
+    for (int e = 0; e < HS; ++e) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0[e], x0[e], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0[e], x1[e], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1[e], x0[e], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1[e], x1[e], acc[1][1], 0, 0, 0);
+    }
+  };
+
+  // bias gradient rides along for free: the Z fragments a lane already holds are column values of rows 2e + kh, so the
+  // column sums over the primal rows (row % group == 0; tiles start at multiples of 32) are plain adds on registers --
+  // every k-step for group 1, lanes kh == 0 for group 2, and additionally only even k-steps for group 4.
   const bool do_bias = g.db_partial != nullptr && k0 == 0;
-  const int bcol = threadIdx.x & 127, bhalf = threadIdx.x >> 7;
-  float bsum = 0.f;
+  const float wodd = g.group == 4 ? 0.f : 1.f;
+  float bsum0 = 0.f, bsum1 = 0.f;
+  auto bias_half = [&](const float (&z0)[HS], const float (&z1)[HS]) {
+#pragma unroll
+    for (int e = 0; e < HS; ++e) {
+      if (e & 1) { bsum0 += wodd * z0[e]; bsum1 += wodd * z1[e]; }
+      else { bsum0 += z0[e]; bsum1 += z1[e]; }
+    }
+  };
   const int nsteps = (r_end - r_begin + TBR - 1) / TBR;
-  if (nsteps > 0) {
+  if (nsteps > 0) {   // (block-uniform)
     load(r_begin);
-    store(0);
-  }
-  __syncthreads();
-  for (int t = 0; t < nsteps; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nsteps) load(r_begin + (t + 1) * TBR);
-    const float* zb = &Zs[cur][kh * TLD + wm * 64 + li];
-    const float* xb = &Xs[cur][kh * TLD + wn * 64 + li];
-    // fragment reads are issued in blocks of 4 row pairs ahead of their 16 MFMAs (the compiler otherwise reuses one
-    // register quad and exposes an LDS round trip every 4 MFMAs)
+    store(0, r_begin);
+    load(r_begin + TBR);
+    __syncthreads();
+    read_half(0, 0, z0a, z1a, x0a, x1a);
+    // Step t, as in the NT kernel: tile t+1 goes registers -> LDS, the register stage is refilled with tile t+2, the second
+    // half's fragments are read -- every memory instruction slotted between two MFMAs of the first half -- then the one
+    // barrier, the first-half fragments of tile t+1, and the second half of the MFMAs.
+    for (int t = 0; t < nsteps; ++t) {
+      const int cur = t & 1;
+      store(cur ^ 1, r_begin + (t + 1) * TBR);
+      load(r_begin + (t + 2) * TBR);
+      read_half(cur, 1, z0b, z1b, x0b, x1b);
+      mfma_half(z0a, z1a, x0a, x1a);
 #pragma unroll
-    for (int h = 0; h < TBR / 8; ++h) {
-      float z0[4], z1[4], x0[4], x1[4];
+      for (int i = 0; i < 2 * TLOADS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 2 * (h * 4 + e) * TLD;
-        z0[e] = zb[r]; z1[e] = zb[r + 32]; x0[e] = xb[r]; x1[e] = xb[r + 32];
+      for (int i = 0; i < 2 * TLOADS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4 * HS - 4 * TLOADS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0[e], x0[e], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0[e], x1[e], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1[e], x0[e], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1[e], x1[e], acc[1][1], 0, 0, 0);
-      }
+      bias_half(z0a, z1a);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      read_half(cur ^ 1, 0, z0a, z1a, x0a, x1a);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_half(z0b, z1b, x0b, x1b);
+      bias_half(z0b, z1b);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (do_bias) {
-      const int rbase = r_begin + t * TBR;
-#pragma unroll
-      for (int row = 0; row < TBR / 2; ++row) {
-        const int r = 2 * row + bhalf;
-        if ((rbase + r) % g.group == 0) bsum += Zs[cur][r * TLD + bcol];   // rows beyond r_end were zero-filled
-      }
-    }
-    if (t + 1 < nsteps) store(cur ^ 1);
-    __syncthreads();
   }
-  if (do_bias) {
-    float* red = &Xs[0][0];
-    red[threadIdx.x] = bsum;
+  __syncthreads();
+  if (do_bias) {   // (block-uniform) waves wn == 0 hold all 128 columns; fold the two row parities
+    float* red = Xs(0);
+    if (wn == 0) {
+      const bool use = kh == 0 || g.group == 1;
+      red[kh * 128 + wm * 64 + li] = use ? bsum0 : 0.f;
+      red[kh * 128 + wm * 64 + 32 + li] = use ? bsum1 : 0.f;
+    }
     __syncthreads();
     if (threadIdx.x < 128 && n0 + threadIdx.x < g.N) g.db_partial[(int64_t)split * g.N + n0 + threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 128];
   }
@@ -565,7 +598,7 @@ int sr_mlp_gemm_tn(const sr_gemm_tn_args* a, void* stream) {
   int rows_per_split = (int)sr_cdiv(a->R, a->splits);
   rows_per_split = (int)(sr_cdiv(rows_per_split, TBR) * TBR);
   if (a->R > 0)
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * a->splits), dim3(256), 0, (hipStream_t)stream, *a, rows_per_split);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * a->splits), dim3(256), TN_LDS_FLOATS * sizeof(float), (hipStream_t)stream, *a, rows_per_split);
   const int64_t total = (int64_t)a->N * a->lddw;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(sr_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, a->partial, a->dW,
                      a->N, a->K, a->lddw, a->R > 0 ? a->splits : 0, a->accumulate);
