@@ -547,16 +547,18 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
     const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));
     hipLaunchKernelGGL((gemm_nt_kernel<4, 1, 2, 1>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), (hipStream_t)stream, g);
   } else {
-    // a round = every CU holding `per_cu` tiles that share its MFMA pipes; its duration ~ per_cu * bm * bn / eff
-    auto cost = [&](int bm, int bn, int per_cu, double eff) {
-      const double wgs = (double)sr_cdiv(g.M, bm) * (double)sr_cdiv(ncols, bn);
-      const double rounds = (double)sr_cdiv((int64_t)wgs, 256 * per_cu);
-      return rounds * per_cu * bm * bn / eff;
+    // The workgroups resident on a CU share its four MFMA pipes, so a CU's time is (tiles it receives) x (tile work):
+    // cost = ceil(workgroups / 256) * bm * bn / eff, eff = measured large-M rate of the configuration relative to 128x128.
+    // (M = 6144, N = 512: 64x64 gives 3 tiles/CU = 12.3k, 64x128 2 tiles/CU = 16.4k, 128x128 1 tile on 192 CUs = 16.4k;
+    // measured 31.5 / 39.9 / 45 us.)
+    auto cost = [&](int bm, int bn, double eff) {
+      const int64_t wgs = sr_cdiv(g.M, bm) * sr_cdiv(ncols, bn);
+      return (double)sr_cdiv(wgs, 256) * bm * bn / eff;
     };
     static const int forced = getenv("SR_NT_CFG") ? atoi(getenv("SR_NT_CFG")) : 0;   // tuning switch
     int pick = forced;
     if (!pick) {
-      const double c[3] = {cost(64, 64, 4, 0.92), cost(64, 128, 2, 0.94), cost(128, 128, 2, 1.0)};   // eff: measured large-M rates / 118 TF
+      const double c[3] = {cost(64, 64, 0.92), cost(64, 128, 0.94), cost(128, 128, 1.0)};
       pick = 1;
       for (int i = 1; i < 3; ++i) if (c[i] < c[pick - 1]) pick = i + 1;
     }

@@ -139,30 +139,66 @@ def _newton(ev, x, bi, rays, cam, group, dthr, athr, w1, w2, update):
     return xnew, conv
 
 
+_PINNED = {}   # device -> pinned int64 scratch for the asynchronous live-ray counts
+COMPACT_BELOW = 0.5   # compact the working set once fewer than this fraction of its rays are still unfinished
+
+
 def OptimizeSurfacePs(cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio, deformer, defconds, dthreshold=5.e-5,
                       athreshold=0.02, w1=3.05, w2=1., times=5):
     """Same contract as the reference: returns (ps, converged) and writes the refined points back
-    into `initTmpPs` (FindSurfacePs.py:152)."""
+    into `initTmpPs` (FindSurfacePs.py:152).
+
+    The reference drops converged rays from the batch after every step (boolean indexing = one host sync per step, 11 a call).
+    Here finished rays stay in the working set, frozen by a device-side mask, and the set is compacted lazily: the count of
+    unfinished rays travels to pinned host memory asynchronously, and only when a count that has ALREADY arrived says that
+    less than COMPACT_BELOW of the set is live does the loop pay the sync of a compaction.  Results are identical -- a
+    finished ray's position and flag never change again -- but the host can run ahead of the GPU through the whole call."""
     with torch.no_grad():
         ev = _FusedEval(tmpSdf, deformer, defconds, ratio)
+        dev = initTmpPs.device
         cam = cam_pos.detach().float().contiguous().view(3)
         rays = rays.detach().float().contiguous()
         P = initTmpPs.shape[0]
-        live = torch.arange(P, device=initTmpPs.device)          # indices of unfinished rays
-        finished = torch.zeros(P, dtype=torch.bool, device=initTmpPs.device)
+        finished = torch.zeros(P, dtype=torch.bool, device=dev)
+        if P == 0:
+            return initTmpPs.detach(), finished
+        pin = _PINNED.get(dev)
+        if pin is None or pin.numel() < times + 2:
+            pin = _PINNED[dev] = torch.zeros(times + 2, dtype=torch.int64).pin_memory()
+        live = None                                   # None: the working set is all rays, in order
+        x = initTmpPs.contiguous().float()
+        bi_l, rays_l = batch_inds.contiguous(), rays
+        done = torch.zeros(P, dtype=torch.bool, device=dev)
+        counts = []                                   # (event, slot, size of the working set when it was taken)
         for it in range(times + 1):
-            if live.numel() == 0:
+            # lazy compaction on the newest count that has already landed on the host
+            while len(counts) > 1 and counts[1][0].query():
+                counts.pop(0)
+            if counts and counts[0][0].query() and counts[0][2] == x.shape[0] and int(pin[counts[0][1]]) < COMPACT_BELOW * x.shape[0]:
+                keep = (~done).nonzero(as_tuple=False).view(-1)          # the one sync, taken only when it pays
+                if live is None:
+                    initTmpPs.copy_(x); finished.copy_(done); live = keep
+                else:
+                    initTmpPs[live] = x; finished[live] = done; live = live[keep]
+                x, bi_l, rays_l = x[keep].contiguous(), bi_l[keep].contiguous(), rays_l[keep].contiguous()
+                done = torch.zeros(keep.numel(), dtype=torch.bool, device=dev)
+                counts = []
+            if x.shape[0] == 0:
                 break
-            x = initTmpPs[live].contiguous().float()
             last = it == times
             if REVERSE_MODE:
-                xnew, conv = _newton_reverse(ev, x, batch_inds[live].contiguous(), rays[live].contiguous(), cam, dthreshold, athreshold,
-                                             w1, w2, not last)
+                xnew, conv = _newton_reverse(ev, x, bi_l, rays_l, cam, dthreshold, athreshold, w1, w2, not last)
             else:
-                xnew, conv = _newton(ev, x, batch_inds[live].contiguous(), rays[live].contiguous(), cam, 1 if last else 4,
-                                     dthreshold, athreshold, w1, w2, not last)
-            finished[live[conv]] = True
+                xnew, conv = _newton(ev, x, bi_l, rays_l, cam, 1 if last else 4, dthreshold, athreshold, w1, w2, not last)
             if not last:
-                initTmpPs[live] = xnew
-                live = live[~conv]                                # compaction (device nonzero -> one sync per iteration)
+                x = torch.where(done[:, None], x, xnew)    # rays finished before this step stay where they were
+            done = done | conv
+            if not last:
+                pin[it].copy_((~done).sum(), non_blocking=True)
+                e = torch.cuda.Event(); e.record()
+                counts.append((e, it, x.shape[0]))
+        if live is None:
+            initTmpPs.copy_(x); finished.copy_(done)
+        else:
+            initTmpPs[live] = x; finished[live] = done
     return initTmpPs.detach(), finished
