@@ -182,11 +182,6 @@ class OptimNetwork(nn.Module):
                 batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(self.TmpVs.detach(), self.Tmpfs, frags)
             else:
                 batch_inds, row_inds, col_inds, initTmpPs = self._seed_rays(defTmpVs.detach(), cameras, H, W)
-        masks = self._silhouette(defTmpVs, cameras, H, W, self.point_radius)
-        radius = int(np.round(self.point_radius / 2. * float(min(H, W)) / 1.2))
-        mgtMs = F.max_pool2d(gtMs, kernel_size=2 * radius + 1, stride=1, padding=radius) if radius > 0 else gtMs
-        total_loss = self.computeTmpPcLoss(defTmpVs, defconds, masks, mgtMs, ratio)
-
         sel = gtMs[batch_inds, row_inds, col_inds] > 0.
         batch_inds, row_inds, col_inds, initTmpPs = batch_inds[sel], row_inds[sel], col_inds[sel], initTmpPs[sel]
         pnum = batch_inds.shape[0]
@@ -199,6 +194,16 @@ class OptimNetwork(nn.Module):
 
         pixels = torch.stack([col_inds, row_inds, torch.ones_like(col_inds)], dim=-1).float()
         rays = cameras.view_rays(pixels)
+
+        # The template branch (silhouette, mask loss, its backward, the template SGD step, |f(TmpVs)|) is a few large kernels;
+        # the ray branch below is thousands of small ones whose cost is host-side issue time.  Queue the template branch
+        # AFTER the ray selection's host syncs and BEFORE the refiner, so the GPU chews on it while the host runs ahead
+        # through the (sync-free) refiner.  The reference's order differs only in where the ray-selection random draw sits.
+        masks = self._silhouette(defTmpVs, cameras, H, W, self.point_radius)
+        radius = int(np.round(self.point_radius / 2. * float(min(H, W)) / 1.2))
+        mgtMs = F.max_pool2d(gtMs, kernel_size=2 * radius + 1, stride=1, padding=radius) if radius > 0 else gtMs
+        total_loss = self.computeTmpPcLoss(defTmpVs, defconds, masks, mgtMs, ratio)
+
         poses, trans, d_cond, rendcond = self.dataset.get_grad_parameters(frame_ids, device)
         defconds = [d_cond, [poses, trans]]
         initTmpPs, check = OptimizeSurfacePs(cameras.cam_pos().detach(), rays.detach(), initTmpPs.contiguous(), batch_inds, self.sdf, ratio,
