@@ -483,26 +483,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
 }
 
-// dW = (accumulate ? dW : 0) + sum_s partial[s]; padding columns [K, lddw) are written as 0.
+// dW = (accumulate ? dW : 0) + sum_s partial[s]; padding columns [K, lddw) are written as 0.  The same launch folds the
+// bias-gradient partials (indices past N * lddw): db = (accumulate ? db : 0) + sum_s db_partial[s].
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int N,
-                                                           int K, int64_t lddw, int splits, int accumulate) {
+                                                           int K, int64_t lddw, int splits, int accumulate,
+                                                           const float* __restrict__ db_partial, float* __restrict__ db) {
   const int64_t total = (int64_t)N * lddw;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int col = (int)(i % lddw);
-    float s = 0.f;
-    if (col < K)
-      for (int p = 0; p < splits; ++p) s += partial[(int64_t)p * total + i];
-    dW[i] = (accumulate ? dW[i] : 0.f) + s;
+  const int64_t all = total + (db ? N : 0);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < all; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < total) {
+      const int col = (int)(i % lddw);
+      float s = 0.f;
+      if (col < K)
+        for (int p = 0; p < splits; ++p) s += partial[(int64_t)p * total + i];
+      dW[i] = (accumulate ? dW[i] : 0.f) + s;
+    } else {
+      const int n = (int)(i - total);
+      float s = 0.f;
+      for (int p = 0; p < splits; ++p) s += db_partial[(int64_t)p * N + n];
+      db[n] = (accumulate ? db[n] : 0.f) + s;
+    }
   }
-}
-
-__global__ __launch_bounds__(256) void bias_reduce_kernel(const float* __restrict__ partial, float* __restrict__ db, int N, int splits,
-                                                           int accumulate) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float s = 0.f;
-  for (int p = 0; p < splits; ++p) s += partial[(int64_t)p * N + n];
-  db[n] = (accumulate ? db[n] : 0.f) + s;
 }
 
 // out[n] = sum over primal rows (r % group == 0) of Z[r][n]; one workgroup per 64 columns x row-slice,
@@ -601,12 +602,9 @@ int sr_mlp_gemm_tn(const sr_gemm_tn_args* a, void* stream) {
   rows_per_split = (int)(sr_cdiv(rows_per_split, TBR) * TBR);
   if (a->R > 0)
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * a->splits), dim3(256), TN_LDS_FLOATS * sizeof(float), (hipStream_t)stream, *a, rows_per_split);
-  const int64_t total = (int64_t)a->N * a->lddw;
+  const int64_t total = (int64_t)a->N * a->lddw + (a->db ? a->N : 0);
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(sr_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, a->partial, a->dW,
-                     a->N, a->K, a->lddw, a->R > 0 ? a->splits : 0, a->accumulate);
-  if (a->db && a->db_partial)
-    hipLaunchKernelGGL(bias_reduce_kernel, dim3((unsigned)sr_cdiv(a->N, 256)), dim3(256), 0, (hipStream_t)stream, a->db_partial, a->db,
-                       a->N, a->R > 0 ? a->splits : 0, a->accumulate);
+                     a->N, a->K, a->lddw, a->R > 0 ? a->splits : 0, a->accumulate, a->db_partial, a->db);
   return sr_launch_status();
 }
 

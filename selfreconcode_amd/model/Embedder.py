@@ -39,16 +39,27 @@ class PEFunction(torch.autograd.Function):
                       _lib.ptr(extra_index), 1, _lib.ptr(out), ldo, _lib.stream_of(x))
         ctx.L, ctx.E, ctx.segment = L, E, segment
         ctx.n_extra = 0 if extra is None else extra.shape[0]
-        ctx.save_for_backward(out, extra_index)
+        ctx.wt = wt
+        ctx.save_for_backward(out, extra_index, x)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        out, extra_index = ctx.saved_tensors
+        out, extra_index, x = ctx.saved_tensors
         L, E = ctx.L, ctx.E
         P = out.shape[0]
-        gx = g[:, :3]
-        if L > 0:
+        if not torch.is_grad_enabled() and ctx.needs_input_grad[0]:
+            # plain first-order backward: one kernel instead of ~10 elementwise launches (the composite below is kept for
+            # create_graph=True, where the backward itself must be differentiable)
+            g = g.contiguous()
+            gx = torch.empty_like(x)
+            with torch.cuda.device(x.device):
+                _lib.call("sr_pe_embed_bwd", _lib.ptr(x), P, L, _lib.ptr(ctx.wt), 1, _lib.ptr(g), g.stride(0), _lib.ptr(gx), _lib.stream_of(x))
+        elif not ctx.needs_input_grad[0]:
+            gx = None
+        else:
+            gx = g[:, :3]
+        if L > 0 and gx is not None and torch.is_grad_enabled():
             Eb = out[:, 3:3 + 6 * L].reshape(P, L, 2, 3)
             gb = g[:, 3:3 + 6 * L].reshape(P, L, 2, 3)
             f = (2.0 ** torch.arange(L, device=out.device, dtype=out.dtype)).view(1, L, 1)

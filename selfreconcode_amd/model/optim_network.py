@@ -182,13 +182,14 @@ class OptimNetwork(nn.Module):
                 batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(self.TmpVs.detach(), self.Tmpfs, frags)
             else:
                 batch_inds, row_inds, col_inds, initTmpPs = self._seed_rays(defTmpVs.detach(), cameras, H, W)
-        sel = gtMs[batch_inds, row_inds, col_inds] > 0.
+        # boolean masks are turned into index lists ONCE (each `x[mask]` is its own nonzero + host sync)
+        sel = (gtMs[batch_inds, row_inds, col_inds] > 0.).nonzero(as_tuple=False).view(-1)
         batch_inds, row_inds, col_inds, initTmpPs = batch_inds[sel], row_inds[sel], col_inds[sel], initTmpPs[sel]
         pnum = batch_inds.shape[0]
         sample_pix = self.conf.get_int('sample_pix_num') if 'sample_pix_num' in self.conf else sample_pix
         if pnum > sample_pix * N:
             u = rand['ray_select'] if 'ray_select' in rand else torch.rand(pnum, device=device)
-            sel = u < float(sample_pix * N) / float(pnum)
+            sel = (u < float(sample_pix * N) / float(pnum)).nonzero(as_tuple=False).view(-1)
             batch_inds, row_inds, col_inds, initTmpPs = batch_inds[sel], row_inds[sel], col_inds[sel], initTmpPs[sel]
             pnum = batch_inds.shape[0]
 
@@ -235,12 +236,13 @@ class OptimNetwork(nn.Module):
 
         # --- colour + normal branches on the converged rays (network.py:599-639)
         self.info['color_loss'] = -1.0
-        nconv = int(check.sum())            # one host sync: sizes of the boolean gathers below
+        conv_idx = check.nonzero(as_tuple=False).view(-1)     # one host sync for all the gathers below
+        nconv = conv_idx.numel()
         if nconv > 0:
-            self.TmpPs = initTmpPs[check]
+            self.TmpPs = initTmpPs[conv_idx]
             self.TmpPs.requires_grad = True
-            self.rays = rays[check]
-            self.batch_inds, self.col_inds, self.row_inds = batch_inds[check], col_inds[check], row_inds[check]
+            self.rays = rays[conv_idx]
+            self.batch_inds, self.col_inds, self.row_inds = batch_inds[conv_idx], col_inds[conv_idx], row_inds[conv_idx]
             extra = self.loss_color_normal(datas, gtCs, cameras, defconds, rendcond, ratio, N)
             total_loss = total_loss + extra
 
@@ -312,7 +314,11 @@ class OptimNetwork(nn.Module):
             grad_d_p = U.compute_Jacobian(self.TmpPs, ds, True, True)
             gtnormals = (grad_d_p.transpose(-2, -1) @ gtnormals.view(-1, 3, 1)).view(-1, 3)
             normal_loss = (gtnormals - nx).norm(2, dim=1) * weights
-            normal_loss = scatter_mean(normal_loss[valid_mask], self.batch_inds[valid_mask], N).mean()
+            # scatter-mean over the valid rows without materialising the subset (no host sync): masked sums / masked counts
+            zero = torch.zeros((), dtype=normal_loss.dtype, device=device)
+            ssum = torch.zeros(N, dtype=normal_loss.dtype, device=device).index_add(0, self.batch_inds, torch.where(valid_mask, normal_loss, zero))
+            scnt = torch.zeros(N, dtype=normal_loss.dtype, device=device).index_add(0, self.batch_inds, valid_mask.to(normal_loss.dtype))
+            normal_loss = (ssum / scnt.clamp(min=1)).mean()
             self.info['normal_loss'] = normal_loss.detach()
             total = total + self.conf.get_float('normal_weight') * normal_loss
         return total

@@ -89,6 +89,9 @@ def sample_points(pc_input, global_sigma, local_sigma, ratio=6):
     return sample_local
 
 
+SINGULAR_COUNT = {}   # device scalars: singular deformation Jacobians seen by the last calls (read them to sync)
+
+
 def compute_Jacobian(ps, ds, retain_graph, create_graph, allow_unused=False):
     """utils/utils.py:106-120 -- three reverse passes (generic drop-in path; the fused step uses the
     forward-mode group-4 kernels instead, see model/Deformer.py)."""
@@ -112,13 +115,10 @@ def compute_deformed_normals(sdf, deformer, ps, defconds, batch_inds, ratio, pha
     grad_d_p = compute_Jacobian(ps, ds, check, check)
     grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
     nx = grad_d_p_inv.transpose(-2, -1).matmul(onx.view(-1, 3, 1)).view(-1, 3)
-    n_inv_mask = ~inv_mask
-    if n_inv_mask.sum().item() > 0:
-        print('unwished error n_inv_mask:(%d:%d)' % (n_inv_mask.sum().item(), n_inv_mask.numel()))
-        nnx = torch.zeros_like(nx)
-        nnx[inv_mask] = nx[inv_mask]
-        nnx[n_inv_mask] = grad_d_p[n_inv_mask].matmul(onx[n_inv_mask].unsqueeze(-1)).view(-1, 3)
-        nx = nnx
+    # singular Jacobians fall back to J n (reference :145-150).  The reference tests the mask on the host and prints a warning
+    # (one sync per call); here the selection is a device-side where() and the count is left in SINGULAR_COUNT for whoever asks.
+    SINGULAR_COUNT['normals'] = (~inv_mask).sum()
+    nx = torch.where(inv_mask[:, None], nx, grad_d_p.matmul(onx.unsqueeze(-1)).view(-1, 3))
     nx = nx / nx.norm(dim=1, keepdim=True)
     return nx, ds
 
@@ -130,13 +130,8 @@ def compute_cardinal_rays(deformer, ps, rays, defconds, batch_inds, ratio, phase
     grad_d_p = compute_Jacobian(ps, ds, check, check)
     grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
     crays = grad_d_p_inv.matmul(rays.view(-1, 3, 1)).view(-1, 3)
-    n_inv_mask = ~inv_mask
-    if n_inv_mask.sum().item() > 0:
-        print('unwished error n_inv_mask:(%d:%d)' % (n_inv_mask.sum().item(), n_inv_mask.numel()))
-        ncrays = torch.zeros_like(crays)
-        ncrays[inv_mask] = crays[inv_mask]
-        ncrays[n_inv_mask] = rays[n_inv_mask].detach()
-        crays = ncrays
+    SINGULAR_COUNT['rays'] = (~inv_mask).sum()          # (reference :162-167: host test + print; see compute_deformed_normals)
+    crays = torch.where(inv_mask[:, None], crays, rays.detach())
     crays = crays / crays.norm(dim=1, keepdim=True)
     return crays, ds
 

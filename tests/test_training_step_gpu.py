@@ -185,7 +185,12 @@ def test_color_normal_losses_and_propagation_vs_oracle():
     assert int(net.info['invInfo'][1]) == int(ok.sum())
     close(net.sdf.lin2.weight_v.grad, sdf_o["lin2.weight_v"].grad); close(net.sdf.lin8.bias.grad, sdf_o["lin8.bias"].grad)
     close(net.deformer.defs[0].lin0.weight.grad, trp["lin0.weight"].grad)
-    close(net.dataset.poses.grad[fids], pso.grad); close(net.dataset.trans.grad[fids], tso.grad); close(net.dataset.conds[0].grad[fids], co.grad)
+    # per-frame pose / translation / code gradients are sums over every ray of the frame with heavy cancellation: fp32
+    # summation order (wave-level partial sums on the GPU, sequential on the CPU oracle) moves them by a few 1e-4 of the
+    # largest entry
+    def close_sum(a, b):
+        close(a, b, rtol=1e-3, atol=1e-3 * max(1e-3, float(b.detach().abs().max())))
+    close_sum(net.dataset.poses.grad[fids], pso.grad); close_sum(net.dataset.trans.grad[fids], tso.grad); close_sum(net.dataset.conds[0].grad[fids], co.grad)
 
 
 def test_deferred_gradients_equal_plain_autograd_over_a_full_iteration():
