@@ -33,7 +33,8 @@ def _worker(rank, world, port, out):
     bucket.all_reduce_mean()
     tv = torch.full((5, 3), float(rank + 1))
     srdist.all_reduce_mean_(tv)
-    out.put((rank, [p.grad.clone() for p in params], tv))
+    # by value (numpy): a tensor on a multiprocessing queue travels as a shared-memory handle that dies with this process
+    out.put((rank, [p.grad.numpy().copy() for p in params], tv.numpy().copy()))
     dist.destroy_process_group()
 
 
@@ -45,6 +46,7 @@ def test_two_rank_gradient_allreduce_matches_full_batch():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = [(r, [torch.from_numpy(g) for g in gs], torch.from_numpy(tv)) for r, gs, tv in res]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
