@@ -77,10 +77,21 @@ class _GemmProfile:
     def __init__(self):
         self.enabled = False
         self.records = []
+        self.pool = []
 
-    def reset(self, enabled):
+    def reset(self, enabled, reserve=0):
+        """`reserve` event pairs are created (and recorded once, which is what allocates the HIP event) ahead of time, so that
+        inside the measured region a pair costs two hipEventRecord calls and nothing else."""
         self.enabled = enabled
         self.records = []
+        self.pool = []
+        for _ in range(reserve if enabled else 0):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); e1.record()
+            self.pool.append((e0, e1))
+
+    def pair(self):
+        return self.pool.pop() if self.pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
     def summary(self):
         if not self.records:
@@ -105,7 +116,7 @@ def _gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, group, act, mode, out_scale=
     a.group, a.act, a.mode, a.out_scale = group, act, mode, out_scale
     a.aux, a.ldaux, a.naux_fwd, a.nact_bwd, a.aux_scale = _lib.ptr(aux), ldaux, naux_fwd, nact_bwd, aux_scale
     if PROFILE.enabled and M >= 128 and N > 32:      # the 128x128-tile kernel only
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = PROFILE.pair()
         e0.record()
         _lib.call("sr_mlp_gemm_nt", ctypes.byref(a), _lib.stream_of(C))
         e1.record()
