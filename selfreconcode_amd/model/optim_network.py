@@ -196,6 +196,16 @@ class OptimNetwork(nn.Module):
         pixels = torch.stack([col_inds, row_inds, torch.ones_like(col_inds)], dim=-1).float()
         rays = cameras.view_rays(pixels)
 
+        # vertex subsets of the eikonal / def-regu samples: the Bernoulli masks do not depend on the vertex positions, so their
+        # index lists (one host sync each) are made here, with the other selection syncs; the gathers happen after the template
+        # step, as in the reference
+        vsel = rand['vert_select'] if 'vert_select' in rand else torch.rand(TmpVnum, device=device)
+        eik_idx = (vsel < 4096. / float(TmpVnum)).nonzero(as_tuple=False).view(-1)
+        use_regu = 'def_regu' in self.conf and self.conf.get_float('def_regu.weight') > 0.
+        if use_regu:
+            vsel2 = rand['vert_select2'] if 'vert_select2' in rand else torch.rand(TmpVnum, device=device)
+            regu_idx = (vsel2 < 4096. / float(TmpVnum)).nonzero(as_tuple=False).view(-1)
+
         # The template branch (silhouette, mask loss, its backward, the template SGD step, |f(TmpVs)|) is a few large kernels;
         # the ray branch below is thousands of small ones whose cost is host-side issue time.  Queue the template branch
         # AFTER the ray selection's host syncs and BEFORE the refiner, so the GPU chews on it while the host runs ahead
@@ -214,16 +224,14 @@ class OptimNetwork(nn.Module):
         self.TmpPs = None
 
         # --- eikonal (network.py:543-549)
-        vsel = rand['vert_select'] if 'vert_select' in rand else torch.rand(TmpVnum, device=device)
-        base = torch.cat([initTmpPs, self.TmpVs[vsel < 4096. / float(TmpVnum)].detach()], dim=0)
+        base = torch.cat([initTmpPs, self.TmpVs.detach()[eik_idx]], dim=0)
         grad_loss = self.loss_eikonal(base, ratio, rand.get('eik_local'), rand.get('eik_global'))
         self.info['grad_loss'] = grad_loss.detach()
         total_loss = total_loss + grad_loss * self.conf.get_float('grad_weight')
 
         # --- deformation regulariser (network.py:565-582)
-        if 'def_regu' in self.conf and self.conf.get_float('def_regu.weight') > 0.:
-            vsel2 = rand['vert_select2'] if 'vert_select2' in rand else torch.rand(TmpVnum, device=device)
-            pts = torch.cat([initTmpPs, self.TmpVs[vsel2 < 4096. / float(TmpVnum)].detach()], dim=0)
+        if use_regu:
+            pts = torch.cat([initTmpPs, self.TmpVs.detach()[regu_idx]], dim=0)
             def_loss = self.loss_def_regu(pts, d_cond, N, ratio, rand.get('regu_local'))
             self.info['def_loss'] = def_loss.detach()
             total_loss = total_loss + def_loss * self.conf.get_float('def_regu.weight')
