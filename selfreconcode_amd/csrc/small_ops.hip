@@ -191,24 +191,62 @@ __device__ __forceinline__ bool bary_of(const Tri& t, float px, float py, float&
   return true;
 }
 
+__device__ __forceinline__ void raster_pixel(const Tri& t, int x, int y, int64_t img, int64_t f, int H, int W, unsigned long long* __restrict__ zbuf) {
+  float b0, b1, b2, d;
+  if (!bary_of(t, (float)x, (float)y, b0, b1, b2, d)) return;
+  const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned int)f;
+  unsigned long long* slot = zbuf + (img * H + y) * W + x;
+  if (key < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, key);   // most fragments lose: skip the RMW
+}
+
+struct Box { int xmin, xmax, ymin, ymax; };
+__device__ __forceinline__ Box tri_box(const Tri& t, int H, int W) {
+  Box b;
+  b.xmin = max(0, (int)ceilf(fminf(t.x0, fminf(t.x1, t.x2)))); b.xmax = min(W - 1, (int)floorf(fmaxf(t.x0, fmaxf(t.x1, t.x2))));
+  b.ymin = max(0, (int)ceilf(fminf(t.y0, fminf(t.y1, t.y2)))); b.ymax = min(H - 1, (int)floorf(fmaxf(t.y0, fmaxf(t.y1, t.y2))));
+  return b;
+}
+
+constexpr int RASTER_SMALL = 32;   // pixel tests a single lane does itself; larger boxes go to the wave-per-triangle pass
+
+// Pass 1: one thread per (image, face).  Almost every triangle of a remeshed template covers 0-2 pixel centres, but a
+// few large ones (grazing angles, coarse remesh levels) would keep one lane looping over thousands of pixels while the
+// other 63 wait: those are queued (their packed id in `big_list`, count in `big_count`) for pass 1b.
 __global__ __launch_bounds__(256) void raster_pass1(const float* __restrict__ pix, const float* __restrict__ z, const int64_t* __restrict__ faces,
-                                                     int64_t nimg, int64_t V, int64_t F, int H, int W, unsigned long long* __restrict__ zbuf) {
+                                                     int64_t nimg, int64_t V, int64_t F, int H, int W, unsigned long long* __restrict__ zbuf,
+                                                     int64_t* __restrict__ big_list, unsigned long long* __restrict__ big_count, int64_t big_cap) {
   const int64_t total = nimg * F;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t img = i / F, f = i % F;
     Tri t;
     if (!load_tri(pix, z, faces, img, V, f, t)) continue;
-    const int xmin = max(0, (int)ceilf(fminf(t.x0, fminf(t.x1, t.x2)))), xmax = min(W - 1, (int)floorf(fmaxf(t.x0, fmaxf(t.x1, t.x2))));
-    const int ymin = max(0, (int)ceilf(fminf(t.y0, fminf(t.y1, t.y2)))), ymax = min(H - 1, (int)floorf(fmaxf(t.y0, fmaxf(t.y1, t.y2))));
-    if (xmax - xmin > 256 || ymax - ymin > 256) continue;     // guard against a degenerate projection covering the image
-    for (int y = ymin; y <= ymax; ++y)
-      for (int x = xmin; x <= xmax; ++x) {
-        float b0, b1, b2, d;
-        if (!bary_of(t, (float)x, (float)y, b0, b1, b2, d)) continue;
-        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(unsigned int)f;
-        unsigned long long* slot = zbuf + (img * H + y) * W + x;
-        if (key < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, key);   // most fragments lose: skip the RMW
-      }
+    const Box b = tri_box(t, H, W);
+    if (b.xmax < b.xmin || b.ymax < b.ymin) continue;
+    if (b.xmax - b.xmin > 256 || b.ymax - b.ymin > 256) continue;     // guard against a degenerate projection covering the image
+    if ((b.xmax - b.xmin + 1) * (b.ymax - b.ymin + 1) > RASTER_SMALL) {
+      const unsigned long long slot = atomicAdd(big_count, 1ull);
+      if ((int64_t)slot < big_cap) { big_list[slot] = i; continue; }
+    }
+    for (int y = b.ymin; y <= b.ymax; ++y)
+      for (int x = b.xmin; x <= b.xmax; ++x) raster_pixel(t, x, y, img, f, H, W, zbuf);
+  }
+}
+
+// Pass 1b: one wave per queued triangle, lanes stride over the pixels of its box.
+__global__ __launch_bounds__(256) void raster_pass1b(const float* __restrict__ pix, const float* __restrict__ z, const int64_t* __restrict__ faces,
+                                                      int64_t V, int64_t F, int H, int W, unsigned long long* __restrict__ zbuf,
+                                                      const int64_t* __restrict__ big_list, const unsigned long long* __restrict__ big_count, int64_t big_cap) {
+  const int64_t n = min((int64_t)*big_count, big_cap);
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t k = wave; k < n; k += nwaves) {
+    const int64_t i = big_list[k];
+    const int64_t img = i / F, f = i % F;
+    Tri t;
+    if (!load_tri(pix, z, faces, img, V, f, t)) continue;
+    const Box b = tri_box(t, H, W);
+    const int bw = b.xmax - b.xmin + 1, npix = bw * (b.ymax - b.ymin + 1);
+    for (int p = lane; p < npix; p += 64) raster_pixel(t, b.xmin + p % bw, b.ymin + p / bw, img, f, H, W, zbuf);
   }
 }
 
@@ -240,7 +278,16 @@ extern "C" int sr_raster_mesh(const float* pix, const float* z, const int64_t* f
   if (!zbuf_u64 || !pix_to_face || !bary || (F > 0 && (!pix || !z || !faces))) return SR_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(zbuf_u64, 0xFF, (size_t)nimg * H * W * 8, st) != hipSuccess) return SR_ELAUNCH;
-  if (F > 0) hipLaunchKernelGGL(raster_pass1, dim3(sr_stream_grid(nimg * F, 256)), dim3(256), 0, st, pix, z, faces, nimg, V, F, H, W, (unsigned long long*)zbuf_u64);
+  if (F > 0) {
+    // scratch for the large-triangle queue lives in the outputs pass 2 overwrites: ids in pix_to_face, the counter in bary[0..1]
+    unsigned long long* big_count = (unsigned long long*)bary;
+    const int64_t big_cap = nimg * H * W;
+    if (hipMemsetAsync(big_count, 0, 8, st) != hipSuccess) return SR_ELAUNCH;
+    hipLaunchKernelGGL(raster_pass1, dim3(sr_stream_grid(nimg * F, 256)), dim3(256), 0, st, pix, z, faces, nimg, V, F, H, W,
+                       (unsigned long long*)zbuf_u64, pix_to_face, big_count, big_cap);
+    hipLaunchKernelGGL(raster_pass1b, dim3(512), dim3(256), 0, st, pix, z, faces, V, F, H, W, (unsigned long long*)zbuf_u64, pix_to_face,
+                       big_count, big_cap);
+  }
   hipLaunchKernelGGL(raster_pass2, dim3(sr_stream_grid(nimg * H * W, 256)), dim3(256), 0, st, pix, z, faces, nimg, V, F, H, W,
                      (const unsigned long long*)zbuf_u64, pix_to_face, bary, zout);
   return sr_launch_status();
