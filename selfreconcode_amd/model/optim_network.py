@@ -125,7 +125,16 @@ class OptimNetwork(nn.Module):
         return RectifiedPerspectiveCameras(focals, princeple_ps, Rs, Ts, image_size=[(W, H)]), H, W
 
     # ------------------------------------------------------------------ rasterisation stand-ins
-    def _seed_rays(self, defTmpVs, cameras, H, W):
+    def _side_stream(self, device):
+        st = getattr(self, "_side_streams", None)
+        if st is None:
+            st = self._side_streams = {}
+        key = str(device)
+        if key not in st:
+            st[key] = torch.cuda.Stream(device=device)
+        return st[key]
+
+    def _seed_rays(self, defTmpVs, cameras, H, W, canonical=None):
         """Stand-in for MeshRasterizer + FindSurfacePs: nearest projected template vertex per pixel (packed
         depth|index min-reduction); the seed is that vertex's canonical position."""
         N, V = defTmpVs.shape[0], defTmpVs.shape[1]
@@ -141,7 +150,7 @@ class OptimNetwork(nn.Module):
         hit = big != torch.iinfo(torch.int64).max
         idx = hit.nonzero(as_tuple=False).view(-1)
         batch_inds = idx // (H * W); row_inds = (idx // W) % H; col_inds = idx % W
-        seeds = self.TmpVs.detach()[big[idx] & 0xFFFFFFFF]
+        seeds = (self.TmpVs.detach() if canonical is None else canonical)[big[idx] & 0xFFFFFFFF]
         return batch_inds, row_inds, col_inds, seeds
 
     def _silhouette(self, defTmpVs, cameras, H, W, radius):
@@ -171,55 +180,70 @@ class OptimNetwork(nn.Module):
         poses, trans, d_cond, rendcond = self.dataset.get_grad_parameters(frame_ids, device)
         defconds = [d_cond, [poses, trans]]
         defTmpVs = self.deformer(self.TmpVs[None, :, :].expand(N, -1, 3), defconds, ratio=ratio)
-
         self.info['pc_loss'] = {}
-        with torch.no_grad():
-            if 'frags' in datas:
-                batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(self.TmpVs.detach(), self.Tmpfs, datas['frags'])
-            elif self.seed_mode == "mesh":            # in-repo hard mesh rasteriser -> FindSurfacePs, as the reference does with pytorch3d
-                pix, z = cameras.project(defTmpVs.detach())
-                frags = rasterize_mesh(pix, z, self.Tmpfs, H, W)
-                batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(self.TmpVs.detach(), self.Tmpfs, frags)
-            else:
-                batch_inds, row_inds, col_inds, initTmpPs = self._seed_rays(defTmpVs.detach(), cameras, H, W)
-        # boolean masks are turned into index lists ONCE (each `x[mask]` is its own nonzero + host sync)
-        sel = (gtMs[batch_inds, row_inds, col_inds] > 0.).nonzero(as_tuple=False).view(-1)
-        batch_inds, row_inds, col_inds, initTmpPs = batch_inds[sel], row_inds[sel], col_inds[sel], initTmpPs[sel]
-        pnum = batch_inds.shape[0]
-        sample_pix = self.conf.get_int('sample_pix_num') if 'sample_pix_num' in self.conf else sample_pix
-        if pnum > sample_pix * N:
-            u = rand['ray_select'] if 'ray_select' in rand else torch.rand(pnum, device=device)
-            sel = (u < float(sample_pix * N) / float(pnum)).nonzero(as_tuple=False).view(-1)
-            batch_inds, row_inds, col_inds, initTmpPs = batch_inds[sel], row_inds[sel], col_inds[sel], initTmpPs[sel]
-            pnum = batch_inds.shape[0]
 
-        pixels = torch.stack([col_inds, row_inds, torch.ones_like(col_inds)], dim=-1).float()
-        rays = cameras.view_rays(pixels)
+        # Two streams.  The template branch (silhouette, mask loss, its backward, the template SGD step, |f(TmpVs)|) is a few
+        # large kernels; the ray selection is a handful of tiny kernels and five host syncs (nonzero), and the refiner after it
+        # is thousands of small launches whose cost is host-side issue time.  So: the template branch is queued FIRST on the
+        # main stream; the selection runs on a side stream that only waits for the deformed template, so its syncs return
+        # while the GPU is still busy with the template branch; the (sync-free) refiner is then issued behind it.
+        # The seeds are taken from the canonical vertices as they are now (the template step moves TmpVs).
+        main = torch.cuda.current_stream(device)
+        side = self._side_stream(device)
+        seedVs = self.TmpVs.detach().clone()
+        fork = torch.cuda.Event()
+        fork.record(main)
 
-        # vertex subsets of the eikonal / def-regu samples: the Bernoulli masks do not depend on the vertex positions, so their
-        # index lists (one host sync each) are made here, with the other selection syncs; the gathers happen after the template
-        # step, as in the reference
-        vsel = rand['vert_select'] if 'vert_select' in rand else torch.rand(TmpVnum, device=device)
-        eik_idx = (vsel < 4096. / float(TmpVnum)).nonzero(as_tuple=False).view(-1)
-        use_regu = 'def_regu' in self.conf and self.conf.get_float('def_regu.weight') > 0.
-        if use_regu:
-            vsel2 = rand['vert_select2'] if 'vert_select2' in rand else torch.rand(TmpVnum, device=device)
-            regu_idx = (vsel2 < 4096. / float(TmpVnum)).nonzero(as_tuple=False).view(-1)
-
-        # The template branch (silhouette, mask loss, its backward, the template SGD step, |f(TmpVs)|) is a few large kernels;
-        # the ray branch below is thousands of small ones whose cost is host-side issue time.  Queue the template branch
-        # AFTER the ray selection's host syncs and BEFORE the refiner, so the GPU chews on it while the host runs ahead
-        # through the (sync-free) refiner.  The reference's order differs only in where the ray-selection random draw sits.
         masks = self._silhouette(defTmpVs, cameras, H, W, self.point_radius)
         radius = int(np.round(self.point_radius / 2. * float(min(H, W)) / 1.2))
         mgtMs = F.max_pool2d(gtMs, kernel_size=2 * radius + 1, stride=1, padding=radius) if radius > 0 else gtMs
         total_loss = self.computeTmpPcLoss(defTmpVs, defconds, masks, mgtMs, ratio)
 
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            with torch.no_grad():
+                if 'frags' in datas:
+                    batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(seedVs, self.Tmpfs, datas['frags'])
+                elif self.seed_mode == "mesh":            # in-repo hard mesh rasteriser -> FindSurfacePs, as the reference does with pytorch3d
+                    pix, z = cameras.project(defTmpVs.detach())
+                    frags = rasterize_mesh(pix, z, self.Tmpfs, H, W)
+                    batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(seedVs, self.Tmpfs, frags)
+                else:
+                    batch_inds, row_inds, col_inds, initTmpPs = self._seed_rays(defTmpVs.detach(), cameras, H, W, seedVs)
+            # boolean masks are turned into index lists ONCE (each `x[mask]` is its own nonzero + host sync)
+            sel = (gtMs[batch_inds, row_inds, col_inds] > 0.).nonzero(as_tuple=False).view(-1)
+            batch_inds, row_inds, col_inds, initTmpPs = batch_inds[sel], row_inds[sel], col_inds[sel], initTmpPs[sel]
+            pnum = batch_inds.shape[0]
+            sample_pix = self.conf.get_int('sample_pix_num') if 'sample_pix_num' in self.conf else sample_pix
+            if pnum > sample_pix * N:
+                u = rand['ray_select'] if 'ray_select' in rand else torch.rand(pnum, device=device)
+                sel = (u < float(sample_pix * N) / float(pnum)).nonzero(as_tuple=False).view(-1)
+                batch_inds, row_inds, col_inds, initTmpPs = batch_inds[sel], row_inds[sel], col_inds[sel], initTmpPs[sel]
+                pnum = batch_inds.shape[0]
+            pixels = torch.stack([col_inds, row_inds, torch.ones_like(col_inds)], dim=-1).float()
+            rays = cameras.view_rays(pixels)
+            initTmpPs = initTmpPs.contiguous()
+            # vertex subsets of the eikonal / def-regu samples: the Bernoulli masks do not depend on the vertex positions, so their
+            # index lists (one host sync each) are made here; the gathers happen after the template step, as in the reference
+            vsel = rand['vert_select'] if 'vert_select' in rand else torch.rand(TmpVnum, device=device)
+            eik_idx = (vsel < 4096. / float(TmpVnum)).nonzero(as_tuple=False).view(-1)
+            use_regu = 'def_regu' in self.conf and self.conf.get_float('def_regu.weight') > 0.
+            regu_idx = None
+            if use_regu:
+                vsel2 = rand['vert_select2'] if 'vert_select2' in rand else torch.rand(TmpVnum, device=device)
+                regu_idx = (vsel2 < 4096. / float(TmpVnum)).nonzero(as_tuple=False).view(-1)
+        main.wait_stream(side)
+        for t in (batch_inds, row_inds, col_inds, initTmpPs, rays, eik_idx, regu_idx, pixels):
+            if t is not None:
+                t.record_stream(main)
+
         poses, trans, d_cond, rendcond = self.dataset.get_grad_parameters(frame_ids, device)
         defconds = [d_cond, [poses, trans]]
-        initTmpPs, check = OptimizeSurfacePs(cameras.cam_pos().detach(), rays.detach(), initTmpPs.contiguous(), batch_inds, self.sdf, ratio,
+        initTmpPs, check = OptimizeSurfacePs(cameras.cam_pos().detach(), rays.detach(), initTmpPs, batch_inds, self.sdf, ratio,
                                              self.deformer, defconds, dthreshold=5.e-5, athreshold=self.angThred, w1=3.05, w2=1.,
                                              times=10)
+        refined = torch.cuda.Event()
+        refined.record(main)
         self.info['rayInfo'] = (check.numel(), check.sum())
         self.TmpPs = None
 
@@ -244,7 +268,13 @@ class OptimNetwork(nn.Module):
 
         # --- colour + normal branches on the converged rays (network.py:599-639)
         self.info['color_loss'] = -1.0
-        conv_idx = check.nonzero(as_tuple=False).view(-1)     # one host sync for all the gathers below
+        # one host sync for all the gathers below -- taken on the side stream, which waits for the refiner only: the eikonal /
+        # def-regu / DCT work queued above keeps the GPU busy while the host learns the count and issues the next branch
+        with torch.cuda.stream(side):
+            side.wait_event(refined)
+            conv_idx = check.nonzero(as_tuple=False).view(-1)
+        main.wait_stream(side)
+        conv_idx.record_stream(main)
         nconv = conv_idx.numel()
         if nconv > 0:
             self.TmpPs = initTmpPs[conv_idx]
