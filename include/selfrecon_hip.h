@@ -224,7 +224,8 @@ int sr_newton_apply(const sr_newton2_args* host_args, void* stream);
  * sdf: [nx,ny,nz] fp32 dense, index i*ny*nz + j*nz + k.  Output ORDER is deterministic: vertices by
  * lattice-edge key (cell*3+dir), faces by (cell, triangle) -- the reference's atomicAdd order is not
  * reproducible even by itself; compare after canonicalisation.  No growing singleton, no
- * 5%-of-cells scratch guess (CudaKernels.cu:590-592): the caller sizes the outputs exactly. */
+ * 5%-of-cells scratch guess (CudaKernels.cu:590-592): the caller sizes the outputs exactly.  `workspace` must be 8-byte
+ * aligned (it holds 64-bit classification planes); verts / faces double as scratch inside sr_mc_emit before they are written. */
 int64_t sr_mc_workspace_bytes(int32_t nx, int32_t ny, int32_t nz);
 int sr_mc_count(const float* sdf, int32_t nx, int32_t ny, int32_t nz, float iso, void* workspace, uint32_t* counts_dev, void* stream);
 int sr_mc_emit(const float* sdf, int32_t nx, int32_t ny, int32_t nz, float iso, const void* workspace, float xstep, float ystep,
@@ -258,7 +259,8 @@ int sr_interp2x3d_bwd_f64(const double* grad_out, int64_t BC, int32_t d, int32_t
  * pix [nimg,V,2] projected pixel coordinates (x = column, y = row; integer = pixel centre), z [nimg,V] camera depth,
  * faces [F,3] int64 shared by all images (rows containing -1 are skipped).  Outputs: pix_to_face [nimg,H,W] int64
  * (packed index img*F + f, -1 = background), bary [nimg,H,W,3] (-1 on background), zout [nimg,H,W] nullable.
- * zbuf_u64: scratch of nimg*H*W 8-byte words.  Third-party behaviour, parity unpinned (no pytorch3d here). */
+ * zbuf_u64: scratch of nimg*H*W 8-byte words; pix_to_face and the (8-byte aligned) head of bary hold the large-triangle
+ * queue until the last pass overwrites them.  Third-party behaviour, parity unpinned (no pytorch3d here). */
 int sr_raster_mesh(const float* pix, const float* z, const int64_t* faces, int64_t nimg, int64_t V, int64_t F, int32_t H, int32_t W,
                    void* zbuf_u64, int64_t* pix_to_face, float* bary, float* zout, void* stream);
 
