@@ -124,6 +124,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (fp32 MFMA 32x32x2 layer GEMM with fused epilogue; 128x128 / 64x128 / 64x64 tiles picked per launch), every launch with >= 128 rows and > 32 columns inside the timed region",
                      "achieved": prof["tflops"], "peak": 157.3, "unit": "TFLOP/s", "frac": round(prof["tflops"] / 157.3, 4),
                      "launches": prof["launches"], "avg_launch_us": prof["avg_us"], "flop_per_launch": prof["avg_flop"],
+                     "achieved_launches_ge_64k_rows": prof.get("tflops_large"), "launches_ge_64k_rows": prof.get("launches_large"),
                      "traffic": None},
     }
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_nt.json")      # PMC passes cannot run inside this process; latest committed collection

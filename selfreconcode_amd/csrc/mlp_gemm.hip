@@ -584,8 +584,10 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
 
 int64_t sr_mlp_gemm_tn_workspace_floats(int32_t R, int32_t N, int64_t lddw, int32_t* splits_out) {
   const int tiles = (int)(sr_cdiv(N, 128) * sr_cdiv(lddw, 128));
-  int splits = (int)sr_cdiv(1024, tiles);            // aim at ~4 workgroups per CU
-  const int max_splits = (int)sr_cdiv(R, 256);       // at least 256 rows per split
+  static const int target = getenv("SR_TN_BLOCKS") ? atoi(getenv("SR_TN_BLOCKS")) : 512;   // tuning switch
+  int splits = (int)sr_cdiv(target, tiles);           // two workgroups per CU are resident (LDS): one full wave of the chip; every
+                                                      // further slab costs a 64 KB partial tile written and read again
+  const int max_splits = (int)sr_cdiv(R, 384);       // at least 384 rows (12 steps) per split
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   if (splits_out) *splits_out = splits;

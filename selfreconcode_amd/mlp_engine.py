@@ -97,11 +97,14 @@ class _GemmProfile:
         if not self.records:
             return {"tflops": 0.0, "launches": 0, "avg_us": 0.0, "avg_flop": 0.0}
         torch.cuda.synchronize()
+        times = [r[0].elapsed_time(r[1]) for r in self.records]
         flop = sum(r[2] for r in self.records)
-        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        ms = sum(times)
         n = len(self.records)
+        big = [(r[2], t) for r, t in zip(self.records, times) if r[3] >= 65536]
+        big_tf = sum(f for f, _ in big) / (sum(t for _, t in big) * 1e-3) / 1e12 if big else 0.0
         return {"tflops": round(flop / (ms * 1e-3) / 1e12, 3), "launches": n, "avg_us": round(ms * 1e3 / n, 3),
-                "avg_flop": round(flop / n, 1)}
+                "avg_flop": round(flop / n, 1), "tflops_large": round(big_tf, 3), "launches_large": len(big)}
 
 
 PROFILE = _GemmProfile()
@@ -120,7 +123,7 @@ def _gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, group, act, mode, out_scale=
         e0.record()
         _lib.call("sr_mlp_gemm_nt", ctypes.byref(a), _lib.stream_of(C))
         e1.record()
-        PROFILE.records.append((e0, e1, 2.0 * M * N * K))
+        PROFILE.records.append((e0, e1, 2.0 * M * N * K, M))
         return
     _lib.call("sr_mlp_gemm_nt", ctypes.byref(a), _lib.stream_of(C))
 
