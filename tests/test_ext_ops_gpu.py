@@ -72,6 +72,30 @@ def test_gridsample_fwd_bwd_dbwd_vs_oracle(dtype, tol, channel_last):
         torch.testing.assert_close(a, b, rtol=tol * 20, atol=tol * 20, msg=lambda m, n=name: f"{n}: {m}")
 
 
+@pytest.mark.parametrize("C", [24, 16, 8, 4, 48])
+def test_gridsample_channel_last_fast_path_value_and_grid_gradient(C):
+    """fp32 channel-last volume that does not require grad: the float4 corner-major kernels (all channel-slab widths) against
+    the oracle and against the generic strided kernels on the same data in the reference's NCDHW layout."""
+    from selfreconcode_amd.MCAcc import GridSamplerMine3dFunction
+    inp, grid = _gs_case(torch.float32, C=C, shape=(9, 13, 7), P=1000, seed=3, span=1.2, channel_last=True)
+    go = fx.det_tensor((1, C, 1, 1, 1000), 7, 1.0)
+    assert inp.stride(1) == 1
+
+    def run(fn, vol, dev):
+        g = grid.to(dev).requires_grad_(True)
+        out = fn(vol.to(dev), g)
+        gg, = torch.autograd.grad(out, [g], go.to(dev))
+        return out.detach().cpu(), gg.detach().cpu()
+
+    out, gg = run(GridSamplerMine3dFunction.apply, inp, DEV)
+    out_d, gg_d = run(GridSamplerMine3dFunction.apply, inp.contiguous(), DEV)          # generic kernels, dense layout
+    out_o, gg_o = run(orc.grid_sample_3d, inp, "cpu")
+    assert torch.equal(out, out_d)                                                       # same per-channel corner order: bit-identical
+    torch.testing.assert_close(out, out_o, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gg, gg_d, rtol=2e-4, atol=2e-4)                           # corner-major dot products: different summation order
+    torch.testing.assert_close(gg, gg_o, rtol=2e-4, atol=2e-4)
+
+
 def test_gridsample_matches_aten_value():
     """the identity the reference leans on: GridSamplerMine == F.grid_sample(border, align_corners=False)"""
     from selfreconcode_amd.ext import GridSamplerMine
