@@ -540,29 +540,11 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
   const int ncols = a->N + (a->mode == SR_EPI_FWD ? a->naux_fwd : 0);
   sr_gemm_args g = *a;
   if (g.mode != SR_EPI_FWD) g.naux_fwd = 0;
-  // Tile choice: 256 CUs x (workgroups resident per CU) slots; a launch costs ceil(workgroups / slots) rounds of one tile's
-  // latency.  M = 24k rows (the refiner's group-4 batches) is 764 tiles of 128x128 = 1.5 rounds -> 25% of the chip idles
-  // in the second round; 64x128 tiles make it 3.0 rounds of half-size tiles.  Pick the cheapest by this model.
-  if (ncols <= 32) {
-    using C_ = Cfg<4, 1, 2, 1>;
-    const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));
-    hipLaunchKernelGGL((gemm_nt_kernel<4, 1, 2, 1>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), (hipStream_t)stream, g);
-  } else {
-    // The workgroups resident on a CU share its four MFMA pipes, so a CU's time is (tiles it receives) x (tile work):
-    // cost = ceil(workgroups / 256) * bm * bn / eff, eff = measured large-M rate of the configuration relative to 128x128.
-    // (M = 6144, N = 512: 64x64 gives 3 tiles/CU = 12.3k, 64x128 2 tiles/CU = 16.4k, 128x128 1 tile on 192 CUs = 16.4k;
-    // measured 31.5 / 39.9 / 45 us.)
-    auto cost = [&](int bm, int bn, double eff) {
-      const int64_t wgs = sr_cdiv(g.M, bm) * sr_cdiv(ncols, bn);
-      return (double)sr_cdiv(wgs, 256) * bm * bn / eff;
-    };
-    static const int forced = getenv("SR_NT_CFG") ? atoi(getenv("SR_NT_CFG")) : 0;   // tuning switch
-    int pick = forced;
-    if (!pick) {
-      const double c[3] = {cost(64, 64, 0.92), cost(64, 128, 0.94), cost(128, 128, 1.0)};
-      pick = 1;
-      for (int i = 1; i < 3; ++i) if (c[i] < c[pick - 1]) pick = i + 1;
-    }
+  // Tile choice by a cost model, see below.
+  auto cost = [&](int bm, int bn, double eff) {
+    const int64_t wgs = sr_cdiv(g.M, bm) * sr_cdiv(ncols, bn);
+    return (double)sr_cdiv(wgs, 256) * bm * bn / eff;
+  };
 #define SR_NT_LAUNCH(WM, WN, TM, TN)                                                                                        \
   do {                                                                                                                      \
     using C_ = Cfg<WM, WN, TM, TN>;                                                                                         \
@@ -570,6 +552,25 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
     hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float),     \
                        (hipStream_t)stream, g);                                                                             \
   } while (0)
+  if (ncols <= 32) {
+    // narrow outputs (the 3-wide deformer / render heads, the sdf-only last layer): 256x32 tiles for the template-sized batches,
+    // 64x32 / 32x32 for the refiner's few thousand rows (6k rows are only 24 tiles of 256 rows on 256 CUs)
+    const double c[3] = {cost(32, 32, 0.6), cost(64, 32, 0.8), cost(256, 32, 1.0)};
+    if (c[0] < c[1] && c[0] < c[2]) SR_NT_LAUNCH(1, 1, 1, 1);
+    else if (c[1] < c[2]) SR_NT_LAUNCH(2, 1, 1, 1);
+    else SR_NT_LAUNCH(4, 1, 2, 1);
+  } else {
+    // The workgroups resident on a CU share its four MFMA pipes, so a CU's time is (tiles it receives) x (tile work):
+    // cost = ceil(workgroups / 256) * bm * bn / eff, eff = measured large-M rate of the configuration relative to 128x128.
+    // (M = 6144, N = 512: 64x64 gives 3 tiles/CU = 12.3k, 64x128 2 tiles/CU = 16.4k, 128x128 1 tile on 192 CUs = 16.4k;
+    // measured 31.5 / 39.9 / 45 us.)
+    static const int forced = getenv("SR_NT_CFG") ? atoi(getenv("SR_NT_CFG")) : 0;   // tuning switch
+    int pick = forced;
+    if (!pick) {
+      const double c[3] = {cost(64, 64, 0.92), cost(64, 128, 0.94), cost(128, 128, 1.0)};
+      pick = 1;
+      for (int i = 1; i < 3; ++i) if (c[i] < c[pick - 1]) pick = i + 1;
+    }
     switch (pick) {
       case 1: SR_NT_LAUNCH(2, 2, 1, 1); break;
       case 2: SR_NT_LAUNCH(2, 2, 1, 2); break;
@@ -577,8 +578,8 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
       case 4: SR_NT_LAUNCH(4, 2, 2, 2); break;
       default: SR_NT_LAUNCH(2, 4, 2, 2); break;
     }
-#undef SR_NT_LAUNCH
   }
+#undef SR_NT_LAUNCH
   return sr_launch_status();
 }
 
