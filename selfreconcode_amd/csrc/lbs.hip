@@ -332,41 +332,49 @@ struct ChainConst {
   int parent[24];
 };
 
-// G (3x4 per joint, row-major [R|t]) for one frame into g[24*12]
-__device__ __forceinline__ void chain_forward(const float* __restrict__ pose, const ChainConst& cc, float* g) {
+// Per-pose working arrays (24 joints x 3x4) live in LDS, element-major: element e of thread t at sm[e * CHAIN_T + t].  (As
+// per-thread arrays indexed by the runtime parent table they were scratch memory, and the two kernels, one dependent chain of
+// global round trips per lane, took 77 / 166 us for three poses.)
+constexpr int CHAIN_T = 32;    // poses per workgroup
+struct LdsMat {                // view of one thread's [24*12] array
+  float* base;
+  __device__ __forceinline__ float& operator()(int joint, int e) const { return base[(joint * 12 + e) * CHAIN_T]; }
+};
+
+// G (3x4 per joint, row-major [R|t]) for one frame
+__device__ __forceinline__ void chain_forward(const float* __restrict__ pose, const ChainConst& cc, const LdsMat& g) {
   for (int i = 0; i < 24; ++i) {
     float R[9];
     rodrigues<float>(pose[i * 3], pose[i * 3 + 1], pose[i * 3 + 2], R);
     const float* rel = cc.rel + i * 3;
-    float* gi = g + i * 12;
     if (i == 0) {
-      for (int r = 0; r < 3; ++r) { gi[r * 4] = R[r * 3]; gi[r * 4 + 1] = R[r * 3 + 1]; gi[r * 4 + 2] = R[r * 3 + 2]; gi[r * 4 + 3] = rel[r]; }
+      for (int r = 0; r < 3; ++r) { g(0, r * 4) = R[r * 3]; g(0, r * 4 + 1) = R[r * 3 + 1]; g(0, r * 4 + 2) = R[r * 3 + 2]; g(0, r * 4 + 3) = rel[r]; }
     } else {
-      const float* gp = g + cc.parent[i] * 12;
+      const int pa = cc.parent[i];
       for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) gi[r * 4 + c] = gp[r * 4] * R[c] + gp[r * 4 + 1] * R[3 + c] + gp[r * 4 + 2] * R[6 + c];
-        gi[r * 4 + 3] = gp[r * 4] * rel[0] + gp[r * 4 + 1] * rel[1] + gp[r * 4 + 2] * rel[2] + gp[r * 4 + 3];
+        const float p0 = g(pa, r * 4), p1 = g(pa, r * 4 + 1), p2 = g(pa, r * 4 + 2), p3 = g(pa, r * 4 + 3);
+        for (int c = 0; c < 3; ++c) g(i, r * 4 + c) = p0 * R[c] + p1 * R[3 + c] + p2 * R[6 + c];
+        g(i, r * 4 + 3) = p0 * rel[0] + p1 * rel[1] + p2 * rel[2] + p3;
       }
     }
   }
 }
 
-__global__ __launch_bounds__(64) void chain_fwd_kernel(const float* __restrict__ poses, int B, ChainConst cc, float* __restrict__ G,
-                                                        float* __restrict__ A) {
+__global__ __launch_bounds__(CHAIN_T) void chain_fwd_kernel(const float* __restrict__ poses, int B, ChainConst cc, float* __restrict__ G,
+                                                             float* __restrict__ A) {
+  extern __shared__ float chain_sm[];
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  float g[24 * 12];
+  const LdsMat g{chain_sm + threadIdx.x};
   chain_forward(poses + (int64_t)b * 72, cc, g);
   for (int i = 0; i < 24; ++i) {
-    const float* gi = g + i * 12;
     const float* p = cc.P + i * 12;
     float* go = G + ((int64_t)b * 24 + i) * 16;
     float* ao = A + ((int64_t)b * 24 + i) * 16;
     for (int r = 0; r < 3; ++r) {
-      for (int c = 0; c < 4; ++c) {
-        go[r * 4 + c] = gi[r * 4 + c];
-        ao[r * 4 + c] = gi[r * 4] * p[c] + gi[r * 4 + 1] * p[4 + c] + gi[r * 4 + 2] * p[8 + c] + (c == 3 ? gi[r * 4 + 3] : 0.f);
-      }
+      const float g0 = g(i, r * 4), g1 = g(i, r * 4 + 1), g2 = g(i, r * 4 + 2), g3 = g(i, r * 4 + 3);
+      go[r * 4] = g0; go[r * 4 + 1] = g1; go[r * 4 + 2] = g2; go[r * 4 + 3] = g3;
+      for (int c = 0; c < 4; ++c) ao[r * 4 + c] = g0 * p[c] + g1 * p[4 + c] + g2 * p[8 + c] + (c == 3 ? g3 : 0.f);
     }
     go[12] = go[13] = go[14] = 0.f; go[15] = 1.f;
     ao[12] = ao[13] = ao[14] = 0.f; ao[15] = 1.f;
@@ -374,11 +382,12 @@ __global__ __launch_bounds__(64) void chain_fwd_kernel(const float* __restrict__
 }
 
 // posebar[b,i,:] from the cotangents Abar, Gbar ([B,24,4,4], either nullable)
-__global__ __launch_bounds__(64) void chain_bwd_kernel(const float* __restrict__ poses, int B, ChainConst cc, const float* __restrict__ Abar,
-                                                        const float* __restrict__ Gbar, float* __restrict__ posebar) {
+__global__ __launch_bounds__(CHAIN_T) void chain_bwd_kernel(const float* __restrict__ poses, int B, ChainConst cc, const float* __restrict__ Abar,
+                                                             const float* __restrict__ Gbar, float* __restrict__ posebar) {
+  extern __shared__ float chain_sm[];
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  float g[24 * 12], gb[24 * 12];
+  const LdsMat g{chain_sm + threadIdx.x}, gb{chain_sm + 24 * 12 * CHAIN_T + threadIdx.x};
   const float* pose = poses + (int64_t)b * 72;
   chain_forward(pose, cc, g);
   for (int i = 0; i < 24; ++i) {
@@ -392,29 +401,28 @@ __global__ __launch_bounds__(64) void chain_bwd_kernel(const float* __restrict__
           if (c < 3) s += ab[0] * p[c * 4] + ab[1] * p[c * 4 + 1] + ab[2] * p[c * 4 + 2] + ab[3] * p[c * 4 + 3];
           else s += ab[3];
         }
-        gb[i * 12 + r * 4 + c] = s;
+        gb(i, r * 4 + c) = s;
       }
   }
   for (int i = 23; i >= 0; --i) {
-    const float* gbi = gb + i * 12;
+    float gbi[12];
+    for (int e = 0; e < 12; ++e) gbi[e] = gb(i, e);
     float Rb[9];
     if (i == 0) {
       for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rb[r * 3 + c] = gbi[r * 4 + c];
     } else {
       const int pa = cc.parent[i];
-      const float* gp = g + pa * 12;
-      float* gbp = gb + pa * 12;
       float R[9];
       rodrigues<float>(pose[i * 3], pose[i * 3 + 1], pose[i * 3 + 2], R);
       const float* rel = cc.rel + i * 3;
       // G_i = G_p L_i: Gbar_p += Gbar_i L_i^T (L = [R | rel; 0 1]);  Rbar = G_p[:, :3]^T Gbar_i[:, :3]
       for (int r = 0; r < 3; ++r) {
         for (int c = 0; c < 3; ++c)
-          gbp[r * 4 + c] += gbi[r * 4] * R[c * 3] + gbi[r * 4 + 1] * R[c * 3 + 1] + gbi[r * 4 + 2] * R[c * 3 + 2] + gbi[r * 4 + 3] * rel[c];
-        gbp[r * 4 + 3] += gbi[r * 4 + 3];
+          gb(pa, r * 4 + c) += gbi[r * 4] * R[c * 3] + gbi[r * 4 + 1] * R[c * 3 + 1] + gbi[r * 4 + 2] * R[c * 3 + 2] + gbi[r * 4 + 3] * rel[c];
+        gb(pa, r * 4 + 3) += gbi[r * 4 + 3];
       }
       for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) Rb[r * 3 + c] = gp[0 * 4 + r] * gbi[0 * 4 + c] + gp[1 * 4 + r] * gbi[1 * 4 + c] + gp[2 * 4 + r] * gbi[2 * 4 + c];
+        for (int c = 0; c < 3; ++c) Rb[r * 3 + c] = g(pa, 0 * 4 + r) * gbi[0 * 4 + c] + g(pa, 1 * 4 + r) * gbi[1 * 4 + c] + g(pa, 2 * 4 + r) * gbi[2 * 4 + c];
     }
     Dual R[9];
     Dual tx{pose[i * 3], {1.f, 0.f, 0.f}}, ty{pose[i * 3 + 1], {0.f, 1.f, 0.f}}, tz{pose[i * 3 + 2], {0.f, 0.f, 1.f}};
@@ -444,7 +452,7 @@ extern "C" int sr_lbs_chain_fwd(const float* poses, int32_t B, const float* host
   if (!poses || !G || !A) return SR_EINVAL;
   ChainConst cc;
   if (fill_chain_const(host_Js, host_parents, host_init_pose, cc) != SR_OK) return SR_EINVAL;
-  hipLaunchKernelGGL(chain_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, poses, B, cc, G, A);
+  hipLaunchKernelGGL(chain_fwd_kernel, dim3((B + CHAIN_T - 1) / CHAIN_T), dim3(CHAIN_T), 24 * 12 * CHAIN_T * sizeof(float), (hipStream_t)stream, poses, B, cc, G, A);
   return sr_launch_status();
 }
 
@@ -455,6 +463,7 @@ extern "C" int sr_lbs_chain_bwd(const float* poses, int32_t B, const float* host
   if (!poses || !posebar || (!Abar && !Gbar)) return SR_EINVAL;
   ChainConst cc;
   if (fill_chain_const(host_Js, host_parents, host_init_pose, cc) != SR_OK) return SR_EINVAL;
-  hipLaunchKernelGGL(chain_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, poses, B, cc, Abar, Gbar, posebar);
+  hipLaunchKernelGGL(chain_bwd_kernel, dim3((B + CHAIN_T - 1) / CHAIN_T), dim3(CHAIN_T), 2 * 24 * 12 * CHAIN_T * sizeof(float), (hipStream_t)stream, poses, B, cc, Abar, Gbar,
+                     posebar);
   return sr_launch_status();
 }
