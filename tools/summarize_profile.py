@@ -13,7 +13,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
-stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)   # newest (gpurun merges, never deletes)
 shutil.copy(stats, os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
 for name in ("hbm_kernels.md", "gemm_bench.txt"):
     if os.path.exists(os.path.join(src, name)):
