@@ -183,3 +183,28 @@ def test_sdf_only_variant_matches_full_network():
     # tiny batches take the 64x64-tile kernel: same numbers
     xs = x.detach()[:37].clone().requires_grad_(True)
     close(net(xs, 0.8), full[:37], 1e-6, 1e-7)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 3, 7), (63, 33, 39), (64, 32, 40), (65, 64, 33), (129, 257, 167), (300, 473, 512),
+                                   (1000, 167, 289), (4097, 512, 41), (6129, 3, 512), (257, 31, 65), (8192, 130, 96)])
+def test_gemm_kernels_ragged_shapes_vs_float64(M, N, K):
+    """The layer-GEMM kernels on shapes that hit every clamp of the branch-free loaders (row tails, K tails inside and across
+    float4s, narrow / ragged N, every tile configuration), with NaN planted in all padding the kernels are allowed to read:
+    C = A B^T + b against float64, and dW = Z^T A, db = colsum(Z) likewise."""
+    from selfreconcode_amd import mlp_engine as me
+    g = torch.Generator().manual_seed(M * 7919 + N * 31 + K)
+    ldk, ldn = me.pad4(K) + 4, me.pad4(N) + 8                      # row pitches wider than the logical widths
+    A = torch.full((M, ldk), float("nan")); A[:, :K] = torch.randn(M, K, generator=g)
+    B = torch.full((N, ldk), float("nan")); B[:, :K] = torch.randn(N, K, generator=g) * 0.1
+    bias = torch.randn(N, generator=g)
+    Ad, Bd, bd = A.to(DEV), B.to(DEV), bias.to(DEV)
+    C = torch.full((M, ldn), float("nan"), device=DEV)
+    me._gemm_nt(Ad, ldk, Bd, ldk, C, ldn, M, N, K, bd, 1, me.ACT_NONE, me.EPI_FWD)
+    ref = A[:, :K].double() @ B[:, :K].double().t() + bias.double()
+    torch.testing.assert_close(C[:, :N].cpu().double(), ref, rtol=2e-5, atol=2e-5 * max(1.0, K ** 0.5))
+    # weight / bias gradient: Z [M, N] (pitch ldn), A [M, K] (pitch ldk)
+    Z = torch.full((M, ldn), float("nan")); Z[:, :N] = torch.randn(M, N, generator=g)
+    dW, db = me._gemm_tn(Z.to(DEV), ldn, Ad, ldk, M, N, K, me.pad4(K), 1)
+    torch.testing.assert_close(dW[:, :K].cpu().double(), Z[:, :N].double().t() @ A[:, :K].double(), rtol=2e-5, atol=2e-5 * max(1.0, M ** 0.5))
+    torch.testing.assert_close(db.cpu().double(), Z[:, :N].double().sum(0), rtol=2e-5, atol=2e-5 * max(1.0, M ** 0.5))
+    assert torch.isfinite(dW).all()                                # padding columns [K, pad4(K)) are written as zeros
