@@ -62,6 +62,17 @@ int sr_gridsample3d_bwd_f32(const float* input, sr_tensor5 in_d, const float* gr
 int sr_gridsample3d_bwd_f64(const double* input, sr_tensor5 in_d, const double* grid, sr_tensor5 grid_d,
                             const double* grad_output, sr_tensor5 gout_d,
                             double* grad_input /*nullable*/, sr_tensor5 gin_d, double* grad_grid, void* stream);
+/* fp16 (IEEE binary16 storage, `void*` here; the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF at
+ * GridSamplerMineKernel.cu:931,963,1001): same kernels on the native half type, every arithmetic step rounded to half as
+ * at::Half arithmetic is; grad_input accumulates with a 16-bit CAS add. */
+int sr_gridsample3d_fwd_f16(const void* input, sr_tensor5 in_d, const void* grid, sr_tensor5 grid_d, void* output, sr_tensor5 out_d,
+                            void* stream);
+int sr_gridsample3d_bwd_f16(const void* input, sr_tensor5 in_d, const void* grid, sr_tensor5 grid_d, const void* grad_output,
+                            sr_tensor5 gout_d, void* grad_input /*nullable*/, sr_tensor5 gin_d, void* grad_grid, void* stream);
+int sr_gridsample3d_dbwd_f16(const void* gO_input /*nullable*/, sr_tensor5 goi_d, const void* gO_grid, sr_tensor5 gog_d,
+                             const void* input, sr_tensor5 in_d, const void* grid, sr_tensor5 grid_d, const void* grad_output,
+                             sr_tensor5 gout_d, void* grad_input /*nullable*/, sr_tensor5 gin_d, void* grad_grid,
+                             void* grad_grad_output, void* stream);
 /* double backward: cotangents (gO_input [like input] nullable = zeros, gO_grid [N,Do,Ho,Wo,3]
  * with strides) of the backward's two outputs -> grad_input (nullable, zero-filled by caller),
  * grad_grid (dense), grad_grad_output (dense [N,C,Do,Ho,Wo]). */

@@ -68,6 +68,9 @@ SIGNATURES = {
     "sr_minv3x3_fwd_f64": [_vp, _vp, _vp, _i64, _vp],
     "sr_minv3x3_bwd_f32": [_vp, _vp, _vp, _i64, _vp],
     "sr_minv3x3_bwd_f64": [_vp, _vp, _vp, _i64, _vp],
+    "sr_gridsample3d_fwd_f16": [_vp, _T5, _vp, _T5, _vp, _T5, _vp],
+    "sr_gridsample3d_bwd_f16": [_vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _vp],
+    "sr_gridsample3d_dbwd_f16": [_vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _vp, _vp],
     "sr_gridsample3d_fwd_f32": [_vp, _T5, _vp, _T5, _vp, _T5, _vp],
     "sr_gridsample3d_fwd_f64": [_vp, _T5, _vp, _T5, _vp, _T5, _vp],
     "sr_gridsample3d_bwd_f32": [_vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _vp],

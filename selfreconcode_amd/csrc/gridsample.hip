@@ -122,6 +122,21 @@ __global__ __launch_bounds__(256) void gs_fwd_kernel(int64_t total, const T* __r
 
 template <typename T>
 __device__ __forceinline__ void atomic_add(T* p, T v) { atomicAdd(p, v); }
+// fp16 accumulation (the reference's gpuAtomicAdd on at::Half): CAS on the aligned 32-bit word that holds the element
+template <>
+__device__ __forceinline__ void atomic_add<_Float16>(_Float16* p, _Float16 v) {
+  unsigned int* word = reinterpret_cast<unsigned int*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3);
+  const bool hi = (reinterpret_cast<uintptr_t>(p) & 2) != 0;
+  unsigned int old = *word, assumed;
+  do {
+    assumed = old;
+    const unsigned short bits = hi ? (unsigned short)(assumed >> 16) : (unsigned short)(assumed & 0xFFFFu);
+    const _Float16 sum = __builtin_bit_cast(_Float16, bits) + v;
+    const unsigned int sb = __builtin_bit_cast(unsigned short, sum);
+    const unsigned int repl = hi ? ((assumed & 0x0000FFFFu) | (sb << 16)) : ((assumed & 0xFFFF0000u) | sb);
+    old = atomicCAS(word, assumed, repl);
+  } while (old != assumed);
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void gs_bwd_kernel(int64_t total, const T* __restrict__ input, sr_tensor5 in_d,
@@ -418,6 +433,20 @@ int gs_dbwd(const T* gOi, sr_tensor5 goi_d, const T* gOg, sr_tensor5 gog_d, cons
 }  // namespace
 
 extern "C" {
+// fp16 (the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF, GridSamplerMineKernel.cu:931,963,1001): the same templates
+// on the native _Float16 type -- every +, -, * rounds to half exactly as at::Half arithmetic does (float op, one rounding).
+int sr_gridsample3d_fwd_f16(const void* i, sr_tensor5 id, const void* g, sr_tensor5 gd, void* o, sr_tensor5 od, void* s) {
+  return gs_fwd<_Float16>((const _Float16*)i, id, (const _Float16*)g, gd, (_Float16*)o, od, s);
+}
+int sr_gridsample3d_bwd_f16(const void* i, sr_tensor5 id, const void* g, sr_tensor5 gd, const void* go, sr_tensor5 god, void* gi, sr_tensor5 gid,
+                            void* gg, void* s) {
+  return gs_bwd<_Float16>((const _Float16*)i, id, (const _Float16*)g, gd, (const _Float16*)go, god, (_Float16*)gi, gid, (_Float16*)gg, s);
+}
+int sr_gridsample3d_dbwd_f16(const void* a, sr_tensor5 ad, const void* b, sr_tensor5 bd, const void* i, sr_tensor5 id, const void* g, sr_tensor5 gd,
+                             const void* go, sr_tensor5 god, void* gi, sr_tensor5 gid, void* gg, void* ggo, void* s) {
+  return gs_dbwd<_Float16>((const _Float16*)a, ad, (const _Float16*)b, bd, (const _Float16*)i, id, (const _Float16*)g, gd, (const _Float16*)go, god,
+                           (_Float16*)gi, gid, (_Float16*)gg, (_Float16*)ggo, s);
+}
 int sr_gridsample3d_fwd_f32(const float* i, sr_tensor5 id, const float* g, sr_tensor5 gd, float* o, sr_tensor5 od, void* s) { return gs_fwd<float>(i, id, g, gd, o, od, s); }
 int sr_gridsample3d_fwd_f64(const double* i, sr_tensor5 id, const double* g, sr_tensor5 gd, double* o, sr_tensor5 od, void* s) { return gs_fwd<double>(i, id, g, gd, o, od, s); }
 int sr_gridsample3d_bwd_f32(const float* i, sr_tensor5 id, const float* g, sr_tensor5 gd, const float* go, sr_tensor5 god, float* gi, sr_tensor5 gid, float* gg, void* s) { return gs_bwd<float>(i, id, g, gd, go, god, gi, gid, gg, s); }

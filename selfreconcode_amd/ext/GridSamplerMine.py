@@ -12,7 +12,7 @@ the skinning volume is a buffer); the autograd glue in MCAcc/grid_sampler_mine.p
 import torch
 from .. import _lib
 
-_SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
+_SUFFIX = {torch.float16: "f16", torch.float32: "f32", torch.float64: "f64"}      # AT_DISPATCH_FLOATING_TYPES_AND_HALF
 
 
 def _check(input, grid, interpolation_mode, padding_mode):
@@ -38,7 +38,7 @@ def _check(input, grid, interpolation_mode, padding_mode):
         if input.size(i) <= 0:
             raise RuntimeError("grid_sampler(): expected input to have non-empty spatial dimensions")
     if input.dtype not in _SUFFIX:
-        raise RuntimeError(f"grid_sampler(): dtype {input.dtype} is not built (f32/f64 only; the reference also dispatched f16)")
+        raise RuntimeError(f"grid_sampler(): \"grid_sampler_3d_cuda\" not implemented for '{input.dtype}'")
     _lib.require_gpu(input, grid)
 
 

@@ -96,6 +96,38 @@ def test_gridsample_channel_last_fast_path_value_and_grid_gradient(C):
     torch.testing.assert_close(gg, gg_o, rtol=2e-4, atol=2e-4)
 
 
+def test_gridsample_fp16_dispatch_tracks_fp32():
+    """The reference dispatches the sampler for half as well (GridSamplerMineKernel.cu:931,963,1001).  fp16 run (every step
+    rounded to half, as at::Half arithmetic) against the fp32 oracle on the same half-representable inputs: values to ~2 % of the data range
+    (a coordinate near 8 has a half ulp of 2^-7, which is the interpolation weight's error), gradients to 10-20 % of their scale
+    (they are differences of such weights times the S/2 un-normalisation factor)."""
+    from selfreconcode_amd.MCAcc import GridSamplerMine3dFunction
+    inp, grid = _gs_case(torch.float32, C=6, shape=(9, 8, 7), P=400, seed=11, span=1.1)
+    inp, grid = inp.half(), grid.half()
+    go = fx.det_tensor((1, 6, 1, 1, 400), 8, 1.0).half()
+    u = fx.det_tensor((1, 1, 1, 400, 3), 9, 1.0).half()
+
+    def run(fn, dev, dt):
+        i = inp.to(dev, dt).requires_grad_(True)
+        g = grid.to(dev, dt).requires_grad_(True)
+        out = fn(i, g)
+        gi, gg = torch.autograd.grad(out, [i, g], go.to(dev, dt), create_graph=True)
+        d_i, d_g = torch.autograd.grad((gg * u.to(dev, dt)).sum(), [i, g])
+        return [t.detach().float().cpu() for t in (out, gi, gg, d_i, d_g)]
+
+    ours = run(GridSamplerMine3dFunction.apply, DEV, torch.float16)
+    ref = run(orc.grid_sample_3d, "cpu", torch.float32)
+    assert all(t.dtype == torch.float32 and torch.isfinite(t).all() for t in ours)
+    # out and grad_input are continuous in the coordinates: bounded everywhere.  The grid gradients are piecewise (they jump
+    # at cell faces), and a coordinate rounded to half lands in the neighbouring cell for a few points in a hundred: judge them
+    # by the fraction of elements that agree.
+    for a, b, name, tol, frac in zip(ours, ref, ["out", "grad_input", "grad_grid", "dd_input", "dd_grid"],
+                                     [2e-2, 2e-2, 3e-2, 3e-2, 6e-2], [1.0, 1.0, 0.93, 0.93, 0.90]):
+        scale = max(float(b.abs().max()), 1.0)
+        ok = ((a - b).abs() <= tol * scale).float().mean().item()
+        assert ok >= frac, f"{name}: only {ok:.3f} of the elements within {tol} of the scale {scale:.3e}"
+
+
 def test_gridsample_matches_aten_value():
     """the identity the reference leans on: GridSamplerMine == F.grid_sample(border, align_corners=False)"""
     from selfreconcode_amd.ext import GridSamplerMine
