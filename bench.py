@@ -133,6 +133,11 @@ def main():
             t = json.load(fh)
         out["roofline"]["traffic"] = round(t["traffic_bytes_per_launch"])
         out["roofline"]["traffic_note"] = "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01_pmc_gemm_nt.json)"
+    occ = os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")          # SQ counter pass over one isolated 262144 x 512 x 512 layer (tools/pmc_gemm.py)
+    if os.path.isfile(occ):
+        with open(occ) as fh:
+            o = json.load(fh)
+        out["roofline"]["mfma_pipe_occupancy_isolated_layer"] = o.get("ours NT", {}).get("mfma_pipe_occupancy")
     if world == 1 and not args.no_cpu_baseline:
         from oracle.cpu_baseline import estimate_iteration_seconds       # checker-side code, baseline leg only
         sec, parts, threads = estimate_iteration_seconds(V, rays_total / max(len(conv), 1), FRAMES_PER_RANK,
