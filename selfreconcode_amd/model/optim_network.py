@@ -325,8 +325,12 @@ class OptimNetwork(nn.Module):
         sdfs = self.sdf(self.TmpPs, ratio)
         with mlp_engine.input_grads_only():
             nx = torch.autograd.grad(sdfs, self.TmpPs, torch.ones_like(sdfs), retain_graph=True, create_graph=True)[0]
+        nx_raw = nx
         nx = nx / nx.norm(dim=1, keepdim=True)
-        crays, defVs = U.compute_cardinal_rays(self.deformer, self.TmpPs, self.rays, defconds, self.batch_inds, ratio, 'train')
+        # the deformed points and their Jacobian at TmpPs are shared by the three places the reference recomputes them
+        # (cardinal rays, the detached weighting normals, the normal loss): identical values and gradients, a third of the work
+        jac = {}
+        crays, defVs = U.compute_cardinal_rays(self.deformer, self.TmpPs, self.rays, defconds, self.batch_inds, ratio, 'train', cache=jac)
         if self.conf.get_float('color_weight') > 0.:
             colors = U.compute_netRender_color(self.netRender, self.TmpPs, defVs, nx, crays, self.sdf.rendcond,
                                                None if rendcond is None else rendcond[self.batch_inds], ratio)
@@ -336,7 +340,7 @@ class OptimNetwork(nn.Module):
             total = total + self.conf.get_float('color_weight') * color_loss
         if 'normal' in datas and 'normal_weight' in self.conf and self.conf.get_float('normal_weight') > 0.:
             if 'weighted_normal' in self.conf and self.conf.get_bool('weighted_normal'):
-                cnx, _ = U.compute_deformed_normals(self.sdf, self.deformer, self.TmpPs, defconds, self.batch_inds, ratio, 'test')
+                cnx, _ = U.compute_deformed_normals(self.sdf, self.deformer, self.TmpPs, defconds, self.batch_inds, ratio, 'test', cache=jac, onx=nx_raw)
                 weights = torch.clamp((-self.rays * cnx.detach()).sum(1).detach(), max=1., min=0.) ** 2
             else:
                 weights = torch.ones(nx.shape[0], device=device)
@@ -348,8 +352,7 @@ class OptimNetwork(nn.Module):
             gtnorms = gtnormals.norm(dim=1, keepdim=True)
             valid_mask = (gtnorms > 0.0001)[..., 0]
             gtnormals = torch.where(valid_mask[:, None], gtnormals / gtnorms.clamp(min=1e-12), gtnormals)
-            ds = self.deformer(self.TmpPs, defconds, self.batch_inds, ratio=ratio)
-            grad_d_p = U.compute_Jacobian(self.TmpPs, ds, True, True)
+            grad_d_p = jac['J']
             gtnormals = (grad_d_p.transpose(-2, -1) @ gtnormals.view(-1, 3, 1)).view(-1, 3)
             normal_loss = (gtnormals - nx).norm(2, dim=1) * weights
             # scatter-mean over the valid rows without materialising the subset (no host sync): masked sums / masked counts

@@ -105,14 +105,25 @@ def compute_Jacobian(ps, ds, retain_graph, create_graph, allow_unused=False):
     return torch.cat(grad_d_p, dim=1)
 
 
-def compute_deformed_normals(sdf, deformer, ps, defconds, batch_inds, ratio, phase):
-    """utils/utils.py:132-153."""
-    sdfs = sdf(ps, ratio)
+def compute_deformed_normals(sdf, deformer, ps, defconds, batch_inds, ratio, phase, cache=None, onx=None):
+    """utils/utils.py:132-153.
+
+    `cache` / `onx` (extensions): the colour + normal branch of one iteration evaluates the deformer Jacobian at the same points
+    three times and the SDF gradient twice (network.py:608,610,623,630-631).  A caller may pass the dict filled by
+    `compute_cardinal_rays(..., cache=...)` and the SDF gradient it already has; in 'test' phase (results used detached) their
+    detached values are reused instead of being recomputed -- same numbers, a third of the work."""
     check = phase in ('train', 'Train')
-    with input_grads_only():
-        onx = torch.autograd.grad(sdfs, ps, torch.ones_like(sdfs), retain_graph=check, create_graph=check)[0]
-    ds = deformer(ps, defconds, batch_inds, ratio=ratio)
-    grad_d_p = compute_Jacobian(ps, ds, check, check)
+    if onx is None or check:
+        sdfs = sdf(ps, ratio)
+        with input_grads_only():
+            onx = torch.autograd.grad(sdfs, ps, torch.ones_like(sdfs), retain_graph=check, create_graph=check)[0]
+    else:
+        onx = onx.detach()
+    if cache is not None and 'J' in cache and not check:
+        ds, grad_d_p = cache['ds'].detach(), cache['J'].detach()
+    else:
+        ds = deformer(ps, defconds, batch_inds, ratio=ratio)
+        grad_d_p = compute_Jacobian(ps, ds, check, check)
     grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
     nx = grad_d_p_inv.transpose(-2, -1).matmul(onx.view(-1, 3, 1)).view(-1, 3)
     # singular Jacobians fall back to J n (reference :145-150).  The reference tests the mask on the host and prints a warning
@@ -123,11 +134,17 @@ def compute_deformed_normals(sdf, deformer, ps, defconds, batch_inds, ratio, pha
     return nx, ds
 
 
-def compute_cardinal_rays(deformer, ps, rays, defconds, batch_inds, ratio, phase):
-    """utils/utils.py:155-169."""
+def compute_cardinal_rays(deformer, ps, rays, defconds, batch_inds, ratio, phase, cache=None):
+    """utils/utils.py:155-169.  `cache` (extension): a dict that receives / supplies the deformed points and their Jacobian
+    (keys 'ds', 'J') so that later uses at the same points share them (see compute_deformed_normals)."""
     check = phase in ('train', 'Train')
-    ds = deformer(ps, defconds, batch_inds, ratio=ratio)
-    grad_d_p = compute_Jacobian(ps, ds, check, check)
+    if cache is not None and 'J' in cache:
+        ds, grad_d_p = cache['ds'], cache['J']
+    else:
+        ds = deformer(ps, defconds, batch_inds, ratio=ratio)
+        grad_d_p = compute_Jacobian(ps, ds, check, check)
+        if cache is not None:
+            cache['ds'], cache['J'] = ds, grad_d_p
     grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
     crays = grad_d_p_inv.matmul(rays.view(-1, 3, 1)).view(-1, 3)
     SINGULAR_COUNT['rays'] = (~inv_mask).sum()          # (reference :162-167: host test + print; see compute_deformed_normals)
