@@ -415,9 +415,9 @@ class OptimNetwork(nn.Module):
         p = self.TmpPs
         f = self.sdf(p, ratio, sdf_only=True)
         with mlp_engine.input_grads_only():
-            grad_f_p = torch.autograd.grad(f, p, torch.ones_like(f), retain_graph=False)[0]
+            grad_f_p = torch.autograd.grad(f, p, torch.ones_like(f), retain_graph=True)[0]
         d = self.deformer(p, defconds, self.batch_inds, ratio=ratio)
-        grad_d_p = U.compute_Jacobian(p, d, False, False).detach()
+        grad_d_p = U.compute_Jacobian(p, d, True, False).detach()      # graphs of f and d are kept: they are back-propagated below
         opt_defconds = [t for t in (d_cond, poses, trans) if t.requires_grad]
         v_cross = cross_matrix(v)
         b = torch.cat([grad_f_p.view(-1, 1, 3), v_cross.matmul(grad_d_p)], dim=1)
@@ -428,8 +428,9 @@ class OptimNetwork(nn.Module):
         # The reference builds a surrogate loss sum(param * grad) from three autograd.grad calls and back-propagates it
         # (network.py:773-814); that adds `grad` to every parameter's .grad, which is exactly one backward of
         # (f, d) with the cotangents (-rhs_f, temp).
-        f2 = self.sdf(p.detach(), ratio, sdf_only=True)
-        d2 = self.deformer(p.detach(), defconds, self.batch_inds, ratio=ratio)
+        # (The reference evaluates f and d a second time at p.detach() for this; the weights have not moved since the evaluations
+        # above, so those graphs are reused and the backward is restricted to the learnable leaves -- p itself gets no gradient.)
+        f2, d2 = f, d
         temp = (rhs_1[:, :, -3:].matmul(-v_cross)).view(-1, 3)
         outs, cots = [f2, d2], [(-rhs_1[:, :, 0]).reshape(f2.shape).detach(), temp.detach()]
         if v_live.requires_grad:                      # d/dv of [v]x (d - c): network.py:798-809
@@ -437,5 +438,13 @@ class OptimNetwork(nn.Module):
             outs.append(v_live); cots.append(rhs_1[:, :, -3:].matmul(dc_cross).view(-1, 3).detach())
         if c_live.requires_grad:                      # network.py:811-813
             outs.append(c_live); cots.append((-temp.sum(0)).detach())
-        torch.autograd.backward(outs, cots)
+        lw = getattr(self.dataset, 'learnable_weights', None)
+        if lw is None:
+            torch.autograd.backward(outs, cots)               # (TmpPs.grad also receives a contribution nobody reads)
+        else:
+            leaves, seen = [], set()
+            for t in list(self.sdf.parameters()) + list(self.deformer.parameters()) + list(lw()):
+                if t.requires_grad and t.is_leaf and id(t) not in seen:
+                    seen.add(id(t)); leaves.append(t)
+            torch.autograd.backward(outs, cots, inputs=leaves)
         mlp_engine.flush_param_grads()       # last gradient producer of the step (no-op unless deferred mode is on)
