@@ -191,7 +191,8 @@ class OptimNetwork(nn.Module):
         main = torch.cuda.current_stream(device)
         side = self._side_stream(device)
         seedVs = self.TmpVs.detach().clone()
-        fork = torch.cuda.Event()
+        self.sdf.packed_weights(); self.deformer.defs[0].packed_weights()   # the per-step weight packs are made HERE, on the main
+        fork = torch.cuda.Event()                                           # stream, before the fork: the side stream reads them
         fork.record(main)
 
         masks = self._silhouette(defTmpVs, cameras, H, W, self.point_radius)
@@ -232,18 +233,22 @@ class OptimNetwork(nn.Module):
             if use_regu:
                 vsel2 = rand['vert_select2'] if 'vert_select2' in rand else torch.rand(TmpVnum, device=device)
                 regu_idx = (vsel2 < 4096. / float(TmpVnum)).nonzero(as_tuple=False).view(-1)
+            # the refiner (no autograd, thousands of small launches with 3 tiles per CU) stays on the side stream: it runs
+            # CONCURRENTLY with the template branch, whose large kernels fill the gaps and tails it leaves
+            with torch.no_grad():
+                poses_s, trans_s, d_cond_s, _ = self.dataset.get_grad_parameters(frame_ids, device)
+                initTmpPs, check = OptimizeSurfacePs(cameras.cam_pos().detach(), rays.detach(), initTmpPs, batch_inds, self.sdf, ratio,
+                                                     self.deformer, [d_cond_s, [poses_s, trans_s]], dthreshold=5.e-5,
+                                                     athreshold=self.angThred, w1=3.05, w2=1., times=10)
+            refined = torch.cuda.Event()
+            refined.record(side)
         main.wait_stream(side)
-        for t in (batch_inds, row_inds, col_inds, initTmpPs, rays, eik_idx, regu_idx, pixels):
+        for t in (batch_inds, row_inds, col_inds, initTmpPs, rays, eik_idx, regu_idx, pixels, check):
             if t is not None:
                 t.record_stream(main)
 
         poses, trans, d_cond, rendcond = self.dataset.get_grad_parameters(frame_ids, device)
         defconds = [d_cond, [poses, trans]]
-        initTmpPs, check = OptimizeSurfacePs(cameras.cam_pos().detach(), rays.detach(), initTmpPs, batch_inds, self.sdf, ratio,
-                                             self.deformer, defconds, dthreshold=5.e-5, athreshold=self.angThred, w1=3.05, w2=1.,
-                                             times=10)
-        refined = torch.cuda.Event()
-        refined.record(main)
         self.info['rayInfo'] = (check.numel(), check.sum())
         self.TmpPs = None
 

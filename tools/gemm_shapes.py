@@ -31,5 +31,6 @@ for k,M,N,K,g,mode,e0,e1 in recs:
     key=(k,mb,N,K,g,mode); a=agg[key]; a[0]+=1; a[1]+=e0.elapsed_time(e1); a[2]+=2.0*M*N*K
 tot=sum(a[1] for a in agg.values())
 print('total gemm ms/iter', tot/6)
-for key,a in sorted(agg.items(), key=lambda kv:-kv[1][1])[:28]:
-    print(f"{str(key):55s} calls/it {a[0]/6:6.1f}  ms/it {a[1]/6:7.2f}  TF/s {a[2]/a[1]/1e9:6.1f}")
+for key,a in sorted(agg.items(), key=lambda kv:-(kv[1][1]-kv[1][2]/125e9))[:30]:
+    lost = a[1]/6 - a[2]/6/125e9          # ms per iteration above what 125 TFLOP/s would take
+    print(f"{str(key):55s} calls/it {a[0]/6:6.1f}  ms/it {a[1]/6:7.2f}  TF/s {a[2]/a[1]/1e9:6.1f}  over-125TF {lost:6.2f} ms")
