@@ -78,6 +78,8 @@ class _GemmProfile:
         self.enabled = False
         self.records = []
         self.pool = []
+        self.overlap = False      # set by OptimNetwork.forward while two streams feed the GPU: an event pair then brackets a kernel
+                                  # that shares the machine with the other stream's kernels, not a kernel's own duration
 
     def reset(self, enabled, reserve=0):
         """`reserve` event pairs are created (and recorded once, which is what allocates the HIP event) ahead of time, so that
@@ -98,13 +100,19 @@ class _GemmProfile:
             return {"tflops": 0.0, "launches": 0, "avg_us": 0.0, "avg_flop": 0.0}
         torch.cuda.synchronize()
         times = [r[0].elapsed_time(r[1]) for r in self.records]
-        flop = sum(r[2] for r in self.records)
-        ms = sum(times)
-        n = len(self.records)
-        big = [(r[2], t) for r, t in zip(self.records, times) if r[3] >= 65536]
-        big_tf = sum(f for f, _ in big) / (sum(t for _, t in big) * 1e-3) / 1e12 if big else 0.0
-        return {"tflops": round(flop / (ms * 1e-3) / 1e12, 3), "launches": n, "avg_us": round(ms * 1e3 / n, 3),
-                "avg_flop": round(flop / n, 1), "tflops_large": round(big_tf, 3), "launches_large": len(big)}
+
+        def rate(sel):
+            f = sum(r[2] for r, t, k in zip(self.records, times, sel) if k)
+            ms = sum(t for t, k in zip(times, sel) if k)
+            n = sum(1 for k in sel if k)
+            return (f / (ms * 1e-3) / 1e12 if ms > 0 else 0.0), n, (ms * 1e3 / n if n else 0.0), (f / n if n else 0.0)
+
+        alone = [not r[4] for r in self.records]
+        tf, n, us, fl = rate(alone)                                   # launches that had the GPU to themselves
+        tf_all, n_all, us_all, _ = rate([True] * len(self.records))
+        tf_big, n_big, _, _ = rate([a and r[3] >= 65536 for a, r in zip(alone, self.records)])
+        return {"tflops": round(tf, 3), "launches": n, "avg_us": round(us, 3), "avg_flop": round(fl, 1), "tflops_large": round(tf_big, 3),
+                "launches_large": n_big, "tflops_all": round(tf_all, 3), "launches_all": n_all, "avg_us_all": round(us_all, 3)}
 
 
 PROFILE = _GemmProfile()
@@ -123,7 +131,7 @@ def _gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, group, act, mode, out_scale=
         e0.record()
         _lib.call("sr_mlp_gemm_nt", ctypes.byref(a), _lib.stream_of(C))
         e1.record()
-        PROFILE.records.append((e0, e1, 2.0 * M * N * K, M))
+        PROFILE.records.append((e0, e1, 2.0 * M * N * K, M, PROFILE.overlap))
         return
     _lib.call("sr_mlp_gemm_nt", ctypes.byref(a), _lib.stream_of(C))
 

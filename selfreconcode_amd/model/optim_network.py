@@ -194,6 +194,7 @@ class OptimNetwork(nn.Module):
         self.sdf.packed_weights(); self.deformer.defs[0].packed_weights()   # the per-step weight packs are made HERE, on the main
         fork = torch.cuda.Event()                                           # stream, before the fork: the side stream reads them
         fork.record(main)
+        mlp_engine.PROFILE.overlap = True       # (bench.py's roofline leg: event pairs inside the two-stream window are not kernel durations)
 
         masks = self._silhouette(defTmpVs, cameras, H, W, self.point_radius)
         radius = int(np.round(self.point_radius / 2. * float(min(H, W)) / 1.2))
@@ -243,6 +244,7 @@ class OptimNetwork(nn.Module):
             refined = torch.cuda.Event()
             refined.record(side)
         main.wait_stream(side)
+        mlp_engine.PROFILE.overlap = False
         for t in (batch_inds, row_inds, col_inds, initTmpPs, rays, eik_idx, regu_idx, pixels, check):
             if t is not None:
                 t.record_stream(main)
