@@ -192,10 +192,29 @@ class SyntheticSequence:
         starts = (fids - batchsize // 2).clamp(min=0, max=self.frame_num - batchsize)
         return data[starts.view(-1, 1) + torch.arange(0, batchsize, device=fids.device).view(1, batchsize)], fids - starts
 
+    def attach_consistent_masks(self, net, ratio):
+        """Ground-truth silhouettes that agree with the scene: the initial template, posed for every frame and splatted exactly as
+        the training step does, thresholded at 0.5.  With the analytic ellipse the mask IoU loss starts at 0.5, the template SGD
+        step tears the template off the SDF zero set (|f(TmpVs)| 1e-5 -> 0.13 after ONE step) and hardly a ray converges in the
+        refiner any more -- a workload no real sequence produces: there the masks match the body and nearly every ray converges."""
+        with torch.no_grad():
+            verts, _ = net.discretizeSDF(ratio, None, -net.sdfShrinkRadius)
+            cameras, H, W = net._cameras(1, self.device)
+            masks = []
+            for f in range(self.frame_num):
+                defconds = [self.conds[0][f:f + 1], [self.poses[f:f + 1], self.trans[f:f + 1]]]
+                dv = net.deformer(verts[None], defconds, ratio=ratio)
+                masks.append(net._silhouette(dv, cameras, H, W, net.point_radius)[0] > 0.5)
+            self._masks = torch.stack(masks)
+
     def batch(self, frame_ids):
         """Synthetic observations: an elliptic ground-truth silhouette around the projected body and uniform-noise
         colour / normal images of the right shape."""
         N, H, W, dev = len(frame_ids), self.H, self.W, self.device
+        g = torch.Generator(device=dev); g.manual_seed(1234 + int(frame_ids[0]))
+        if getattr(self, "_masks", None) is not None:          # self-consistent observations, see attach_consistent_masks
+            return {'img': torch.rand((N, H, W, 3), device=dev, generator=g) * 2 - 1, 'mask': self._masks[frame_ids].float(),
+                    'normal': torch.rand((N, H, W, 3), device=dev, generator=g) * 2 - 1}
         ys, xs = torch.meshgrid(torch.arange(H, device=dev).float(), torch.arange(W, device=dev).float(), indexing='ij')
         f = float(self.camera_params['focal_length'][0]); cx = float(self.camera_params['princeple_points'][0]); cy = float(self.camera_params['princeple_points'][1])
         Tz = float(self.camera_params['world2cam_coord_trans'][2])
@@ -206,7 +225,6 @@ class SyntheticSequence:
             uy = cy - f * (float(tr[1]) + float(self.camera_params['world2cam_coord_trans'][1])) / Tz
             rx, ry = f * 0.56 / Tz, f * 0.63 / Tz
             masks.append((((xs - ux) / rx) ** 2 + ((ys - uy) / ry) ** 2 < 1.0).float())
-        g = torch.Generator(device=dev); g.manual_seed(1234 + int(frame_ids[0]))
         return {'img': torch.rand((N, H, W, 3), device=dev, generator=g) * 2 - 1, 'mask': torch.stack(masks),
                 'normal': torch.rand((N, H, W, 3), device=dev, generator=g) * 2 - 1}
 
@@ -216,7 +234,7 @@ COARSE_RESOLUTIONS = [(14 + 1, 20 + 1, 8 + 1), (28 + 1, 40 + 1, 16 + 1), (56 + 1
 
 
 def build_synthetic_scene(device="cuda:0", frame_num=64, H=540, W=540, stage="coarse", resolutions=None, lbs_volume_shape=(65, 225, 129),
-                          conf=None, seed=0):
+                          conf=None, seed=0, consistent_masks=True):
     """SDF (near-sphere geometric init), deformer (MLPTranslator + LBS on a synthetic weight volume), render net,
     Seg3dLossless engine, orchestrator and dataset, wired like model/network.py::getOptNet (:828-909)."""
     from .config import default_config
@@ -245,4 +263,6 @@ def build_synthetic_scene(device="cuda:0", frame_num=64, H=540, W=540, stage="co
     ds = SyntheticSequence(frame_num, H, W, device, seed)
     net.dataset = ds
     net.dctnull = DCTNullSpace(10, 30).to(device)
+    if consistent_masks:
+        ds.attach_consistent_masks(net, {'sdfRatio': 1., 'deformerRatio': 0.5, 'renderRatio': 1.})
     return net, ds, conf
