@@ -672,6 +672,8 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
       case 1: SR_NT_LAUNCH(2, 2, 1, 1); break;
       case 2: SR_NT_LAUNCH(2, 2, 1, 2); break;
       case 3: SR_NT_LAUNCH(2, 2, 2, 2); break;
+      case 4: SR_NT_LAUNCH(4, 2, 2, 2); break;      // 256x128, 8 waves (tuning switch only)
+      case 5: SR_NT_LAUNCH(2, 4, 2, 2); break;      // 128x256, 8 waves (tuning switch only)
       default: SR_NT_LAUNCH(2, 2, 2, 2); break;
     }
   }
