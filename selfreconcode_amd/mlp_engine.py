@@ -199,7 +199,7 @@ def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_g
             if need_param_grad:
                 sink = _deferred_sink(Ws[l], bs[l]) if (DEFERRED_PARAM_GRADS and Ws is not None) else None
                 if sink is not None:          # accumulate straight into the per-step gradient buffers (no autograd traffic)
-                    _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group, dW=sink[0], db=sink[1], accumulate=True)
+                    _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group, dW=sink[0], db=sink[1], accumulate=sink[2])
                 else:
                     dWs[l], dbs[l] = _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group)
             if l > 0:
@@ -445,15 +445,20 @@ def set_deferred_param_grads(flag):
 
 
 def _deferred_sink(W, b):
+    """-> (dW buffer, db buffer, accumulate) or None.  Both buffers are private to the pack entry; the first weight-gradient GEMM
+    after a flush OVERWRITES them (no zero fill), later ones add."""
     e = _ENTRY_BY_PTR.get(W.data_ptr())
     if e is None or b is None or not b.requires_grad or not b.is_leaf or W.shape[0] != e["W"].shape[0]:
         return None
     if e.get("dW") is None:
-        e["dW"] = torch.zeros_like(e["W"])
+        e["dW"] = torch.empty_like(e["W"])
+        e["db"] = torch.empty((e["W"].shape[0],), dtype=torch.float32, device=e["W"].device)
+        e["fresh"] = True
+    accumulate = not e["fresh"]
+    e["fresh"] = False
     e["dirty"] = True
-    if b.grad is None:
-        b.grad = torch.zeros_like(b)
-    return e["dW"], b.grad
+    e["bias"] = b
+    return e["dW"], e["db"], accumulate
 
 
 def flush_param_grads():
@@ -471,7 +476,9 @@ def flush_param_grads():
             w = src[0]
             gw = dW[:, :w.shape[1]]
             w.grad = gw.clone() if w.grad is None else w.grad.add_(gw)
-        dW.zero_()
+        b = e["bias"]
+        b.grad = e["db"].clone() if b.grad is None else b.grad.add_(e["db"])
+        e["fresh"] = True                                  # the next GEMM overwrites the buffers
         e["dirty"] = False
 
 
