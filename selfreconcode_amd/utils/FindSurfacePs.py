@@ -66,6 +66,15 @@ class _FusedEval:
             self.A = self.skin.posed_transforms(poses.detach())
             self.trans = trans.detach().contiguous()
 
+    def unit_cotangent(self, M):
+        """[M,4] rows (1,0,0,0): the cotangent that turns the SDF reverse sweep into grad f; built once per call."""
+        buf = getattr(self, "_unit", None)
+        if buf is None or buf.shape[0] < M:
+            buf = torch.zeros((M, 4), dtype=torch.float32, device=self.conds.device)
+            buf[:, 0] = 1.0
+            self._unit = buf
+        return buf[:M]
+
     def _embed(self, x, L, wt, extra, index, group):
         P = x.shape[0]
         E = 0 if extra is None else extra.shape[1]
@@ -110,7 +119,7 @@ def _newton_reverse(ev, x, bi, rays, cam, dthr, athr, w1, w2, update):
         s = torch.empty((M,), dtype=torch.float32, device=dev)
         a.t_out, a.ld_t, a.s_out = _lib.ptr(t), 4, _lib.ptr(s)
         _lib.call("sr_newton_prepare", ctypes.byref(a), _lib.stream_of(x))
-        ones = torch.zeros((M, 4), dtype=torch.float32, device=dev); ones[:, 0] = 1.0
+        ones = ev.unit_cotangent(M)
         A0bar, _, _ = me.reverse(ev.sdf_spec, A0, ev.sdf_WT, acts, ones, 1, True, False)
         gf = torch.empty_like(x)
         _lib.call("sr_pe_embed_bwd", _lib.ptr(x), M, ev.sdf.multires, _lib.ptr(ev.w_sdf), 1, _lib.ptr(A0bar), A0bar.stride(0), _lib.ptr(gf), _lib.stream_of(x))
@@ -174,7 +183,7 @@ def OptimizeSurfacePs(cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio, defor
             # lazy compaction on the newest count that has already landed on the host
             while len(counts) > 1 and counts[1][0].query():
                 counts.pop(0)
-            if counts and counts[0][0].query() and counts[0][2] == x.shape[0] and int(pin[counts[0][1]]) < COMPACT_BELOW * x.shape[0]:
+            if counts and counts[0][0].query() and counts[0][2] == x.shape[0] and x.shape[0] - int(pin[counts[0][1]]) < COMPACT_BELOW * x.shape[0]:
                 keep = (~done).nonzero(as_tuple=False).view(-1)          # the one sync, taken only when it pays
                 if live is None:
                     initTmpPs.copy_(x); finished.copy_(done); live = keep
@@ -194,7 +203,7 @@ def OptimizeSurfacePs(cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio, defor
                 x = torch.where(done[:, None], x, xnew)    # rays finished before this step stay where they were
             done = done | conv
             if not last:
-                pin[it].copy_((~done).sum(), non_blocking=True)
+                pin[it].copy_(done.sum(), non_blocking=True)            # finished count; live = size - finished
                 e = torch.cuda.Event(); e.record()
                 counts.append((e, it, x.shape[0]))
         if live is None:
