@@ -477,7 +477,11 @@ def flush_param_grads():
             gw = dW[:, :w.shape[1]]
             w.grad = gw.clone() if w.grad is None else w.grad.add_(gw)
         b = e["bias"]
-        b.grad = e["db"].clone() if b.grad is None else b.grad.add_(e["db"])
+        if b.grad is None:                                 # hand the buffer over instead of copying it; a new one is made on demand
+            b.grad = e["db"]
+            e["db"] = torch.empty_like(e["db"])
+        else:
+            b.grad.add_(e["db"])
         e["fresh"] = True                                  # the next GEMM overwrites the buffers
         e["dirty"] = False
 

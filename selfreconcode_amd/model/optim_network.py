@@ -121,8 +121,19 @@ class OptimNetwork(nn.Module):
         return verts, faces
 
     def _cameras(self, N, device):
+        # fixed cameras (no learnable parameter) are built once: quaternion -> R and friends are ~40 tiny launches per call
+        params = getattr(self.dataset, 'camera_params', None)
+        key = None
+        if isinstance(params, dict) and params and all(torch.is_tensor(v) and not v.requires_grad for v in params.values()):
+            key = (N, str(device)) + tuple((k, v.data_ptr(), v._version) for k, v in sorted(params.items()))
+            hit = getattr(self, '_camera_cache', None)
+            if hit is not None and hit[0] == key:
+                return hit[1]
         focals, princeple_ps, Rs, Ts, H, W = self.dataset.get_camera_parameters(N, device)
-        return RectifiedPerspectiveCameras(focals, princeple_ps, Rs, Ts, image_size=[(W, H)]), H, W
+        out = (RectifiedPerspectiveCameras(focals, princeple_ps, Rs, Ts, image_size=[(W, H)]), H, W)
+        if key is not None:
+            self._camera_cache = (key, out)
+        return out
 
     # ------------------------------------------------------------------ rasterisation stand-ins
     def _side_stream(self, device):
@@ -389,8 +400,7 @@ class OptimNetwork(nn.Module):
             self.info['pc_loss']['defconst_loss'] = consistent_loss.detach()
             loss = loss + consistent_loss * cw
         self.TmpOptimizer.zero_grad()
-        loss.backward()
-        mlp_engine.flush_param_grads()       # last gradient producer of the step (no-op unless deferred mode is on)
+        loss.backward()                              # (deferred weight gradients stay in their buffers until propagateTmpPsGrad flushes)
         srdist.all_reduce_mean_(self.TmpVs.grad)     # shared template: exact batch semantics across ranks
         self.TmpOptimizer.step()
         mnfld_pred = self.sdf(self.TmpVs, ratio, sdf_only=True).view(-1)
