@@ -3,7 +3,12 @@
  * edges 0/3/8" vertex rule and the i<NX-1 guard, :492-505 index fix-up with reversed winding,
  * :513-523 vertex scaling).  The reference's atomicAdd order is replaced by plain counters in
  * cell order; tests canonicalise both sides by lattice-edge key anyway.
- * Build: make -C oracle   (gcc, no FMA contraction: -ffp-contract=off).  Never shipped. */
+ * Floating point: built with -ffp-contract=off; the ONE place where contraction changes a result -- the vertex scaling
+ * v*step+min of d_scale_vertices (:517-519), which nvcc's default -fmad=true fuses -- is written as an explicit fmaf
+ * (the `off + t*dir` products of :363-365 are exact, dir being 0 or +-1, so fusing them changes nothing).  Pinned to the
+ * reference's own kernels compiled for the host (oracle/_ref/libmc_ref_fma.so, tests/test_mc_reference_pin.py).
+ * Build: make -C oracle.  Never shipped. */
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include "../selfreconcode_amd/csrc/mc_tables.h"
@@ -83,9 +88,9 @@ int mc_oracle(const float* sdf, int NX, int NY, int NZ, float iso, float xs, flo
       faces[f * 3 + (2 - pid)] = (int64_t)edge_state[(((int64_t)bx * NY + by) * NZ + bz) * 3 + dir];
     }
   for (int64_t v = 0; v < vcount; ++v) {
-    verts[3 * v] = verts[3 * v] * xs + x0;
-    verts[3 * v + 1] = verts[3 * v + 1] * ys + y0;
-    verts[3 * v + 2] = verts[3 * v + 2] * zs + z0;
+    verts[3 * v] = fmaf(verts[3 * v], xs, x0);
+    verts[3 * v + 1] = fmaf(verts[3 * v + 1], ys, y0);
+    verts[3 * v + 2] = fmaf(verts[3 * v + 2], zs, z0);
   }
   *nv = vcount; *nf = fcount;
   free(edge_state); free(ijkd);

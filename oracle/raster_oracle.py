@@ -1,0 +1,162 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the two pytorch3d rasterisation calls on the reference's iteration.
+
+PARITY UNPINNED: the arithmetic lives in a third-party dependency that is not under /root/reference and is not
+installed here -- pytorch3d 0.4.0 (pinned by the reference's README.md:10,21-25).  What follows restates its published
+algorithm (pytorch3d/csrc/rasterize_points/rasterize_points.cu, csrc/rasterize_meshes/rasterize_meshes.cu,
+csrc/utils/geometry_utils.cuh, csrc/compositing/alpha_composite.cu, renderer/points/rasterizer.py,
+renderer/mesh/rasterizer.py at tag v0.4.0) and is anchored on the reference's own call sites:
+
+  * model/network.py:178-190, 497     PointsRasterizer(radius, points_per_pixel=50) + AlphaCompositor, called through
+  * model/CameraMine.py:285-305       PointsRendererWithFrags.forward: weights = 1 - dists2 / r^2, composite, [N,H,W,C]
+  * model/network.py:877-892, 492     MeshRasterizer(blur_radius=0, faces_per_pixel=1, perspective_correct=True,
+                                      clip_barycentric_coords=False, cull_backfaces=False) -> Fragments for FindSurfacePs
+  * model/CameraMine.py:44-70,171-262 RectifiedPerspectiveCameras: screen-space intrinsics -> NDC calibration matrix
+
+Conventions restated here:
+  - view coordinates  X_view = X_world R + T (row vectors);  x_ndc = fx_ndc X/Z + px_ndc with fx_ndc = fx / (W/2),
+    px_ndc = 1 - 1/W - cx / (W/2)  (CameraMine.py:236-241); the rasterisers take z = Z_view (rasterizer.py `transform`);
+  - NDC +x points LEFT and +y UP: pixel (row, col) has its centre at  x = 1 - (2 col + 1)/W,  y = 1 - (2 row + 1)/H
+    (PixToNdc after the  yi = H-1-row, xi = W-1-col  flip of the kernels), i.e. col = cx - fx X/Z in pixel units;
+  - points: skipped when z < 0; covered when dist2 < radius^2 (strict); the K nearest in z are kept, sorted by z;
+  - compositing front to back:  out = sum_k a_k f_k prod_{j<k} (1 - a_j),  idx < 0 entries skipped;
+  - faces: skipped when max z < 0, when |signed area| <= 1e-8, when the pixel is outside the bounding box, or when the
+    (perspective-corrected) depth is < 0; inside test on the perspective-corrected barycentrics, all three > 0 (strict).
+Only square images are restated (the reference's data are 540^2 / 1080^2; pytorch3d 0.4.0 rescales the NDC range of the
+longer side of a non-square image, which the reference's camera class does not follow)."""
+import numpy as np
+import torch
+
+K_EPS = np.float32(1e-8)          # kEpsilon of geometry_utils.cuh
+
+
+def ndc_projection(points_world, focal, princ, R, T, W, H):
+    """RectifiedPerspectiveCameras.transform_points + the rasterisers' z override.  points_world [...,3] (torch, any
+    float dtype; differentiable) -> xy_ndc [...,2], z_view [...]."""
+    view = points_world @ R + T.view(*([1] * (points_world.dim() - 1)), 3)
+    fx, fy = focal[0] / (W / 2.0), focal[1] / (H / 2.0)
+    px, py = 1. - 1. / W - princ[0] / (W / 2.0), 1. - 1. / H - princ[1] / (H / 2.0)
+    z = view[..., 2]
+    return torch.stack([fx * view[..., 0] / z + px, fy * view[..., 1] / z + py], -1), z
+
+
+def pixel_centres_ndc(H, W):
+    assert H == W, "square images only (see the module docstring)"
+    xs = (1.0 - (2.0 * np.arange(W, dtype=np.float32) + 1.0) / np.float32(W)).astype(np.float32)
+    ys = (1.0 - (2.0 * np.arange(H, dtype=np.float32) + 1.0) / np.float32(H)).astype(np.float32)
+    return xs, ys
+
+
+def rasterize_points(xy_ndc, z, H, W, radius, K=50):
+    """rasterize_points.cu (naive kernel; the coarse-to-fine path gives the same fragments while no bin overflows).
+    xy_ndc [N,V,2], z [N,V] float32 arrays.  Returns idx [N,H,W,K] int64 (PACKED index n*V + v, -1 padded),
+    zbuf [N,H,W,K], dists2 [N,H,W,K] (both -1 padded)."""
+    xy = np.asarray(xy_ndc, np.float32); z = np.asarray(z, np.float32)
+    N, V = z.shape
+    xs, ys = pixel_centres_ndc(H, W)
+    r2 = np.float32(radius) * np.float32(radius)
+    idx = -np.ones((N, H, W, K), np.int64); zb = -np.ones((N, H, W, K), np.float32); d2o = -np.ones((N, H, W, K), np.float32)
+    rad_px_x, rad_px_y = float(radius) * W / 2.0 + 1.0, float(radius) * H / 2.0 + 1.0
+    for n in range(N):
+        buckets = {}
+        col = (1.0 - xy[n, :, 0].astype(np.float64)) * W / 2.0 - 0.5
+        row = (1.0 - xy[n, :, 1].astype(np.float64)) * H / 2.0 - 0.5
+        for v in range(V):
+            if not (z[n, v] >= 0) or not np.isfinite(col[v]) or not np.isfinite(row[v]):
+                continue
+            c0, c1 = int(np.floor(col[v] - rad_px_x)), int(np.ceil(col[v] + rad_px_x))
+            r0, r1 = int(np.floor(row[v] - rad_px_y)), int(np.ceil(row[v] + rad_px_y))
+            for r in range(max(r0, 0), min(r1, H - 1) + 1):
+                dy = ys[r] - xy[n, v, 1]
+                for c in range(max(c0, 0), min(c1, W - 1) + 1):
+                    dx = xs[c] - xy[n, v, 0]
+                    dist2 = np.float32(dx * dx) + np.float32(dy * dy)
+                    if dist2 < r2:
+                        buckets.setdefault((r, c), []).append((z[n, v], v, dist2))
+        for (r, c), lst in buckets.items():
+            lst.sort(key=lambda t: (t[0], t[1]))          # nearest in z first; equal depths: lower point index first
+            for k, (zz, v, dd) in enumerate(lst[:K]):
+                idx[n, r, c, k] = n * V + v; zb[n, r, c, k] = zz; d2o[n, r, c, k] = dd
+    return idx, zb, d2o
+
+
+def alpha_composite(idx, alphas, features):
+    """alpha_composite.cu forward.  idx [N,K,H,W] int64 packed, alphas [N,K,H,W], features [C,P] -> [N,C,H,W]."""
+    N, K, H, W = idx.shape
+    out = torch.zeros(N, features.shape[0], H, W, dtype=alphas.dtype)
+    cum = torch.ones(N, H, W, dtype=alphas.dtype)
+    for k in range(K):
+        valid = idx[:, k] >= 0
+        a = torch.where(valid, alphas[:, k], torch.zeros_like(alphas[:, k]))
+        f = features[:, idx[:, k].clamp(min=0)]                       # [C,N,H,W]
+        out = out + (cum * a).unsqueeze(1) * f.permute(1, 0, 2, 3)
+        cum = cum * (1 - a)
+    return out
+
+
+def render_point_silhouette(points_world, focal, princ, R, T, H, W, radius, K=50):
+    """PointsRendererWithFrags.forward of the reference (CameraMine.py:285-305) with one all-ones feature channel, as
+    network.py:495-497 calls it: masks [N,H,W] (= imgs[..., -1] of computeTmpPcLoss :649).  Differentiable with respect
+    to `points_world` through dists2 (what pytorch3d's rasterize_points backward propagates); the fragment selection is
+    made once, without gradient."""
+    N, V = points_world.shape[0], points_world.shape[1]
+    xy, z = ndc_projection(points_world, focal, princ, R, T, W, H)
+    idx, _, _ = rasterize_points(xy.detach().float().numpy(), z.detach().float().numpy(), H, W, radius, K)
+    idx_t = torch.from_numpy(idx)
+    xs, ys = pixel_centres_ndc(H, W)
+    xf = torch.from_numpy(xs).to(xy.dtype).view(1, 1, W, 1); yf = torch.from_numpy(ys).to(xy.dtype).view(1, H, 1, 1)
+    flat = xy.reshape(N * V, 2)
+    p = flat[idx_t.clamp(min=0)]                                       # [N,H,W,K,2]
+    dists2 = (xf - p[..., 0]) ** 2 + (yf - p[..., 1]) ** 2
+    weights = 1 - dists2 / (radius * radius)
+    feats = torch.ones(1, N * V, dtype=xy.dtype)
+    img = alpha_composite(idx_t.permute(0, 3, 1, 2), weights.permute(0, 3, 1, 2), feats)
+    return img[:, 0], idx_t
+
+
+def _edge(px, py, ax, ay, bx, by):
+    """EdgeFunctionForward(p, v0, v1) of geometry_utils.cuh."""
+    return (px - ax) * (by - ay) - (py - ay) * (bx - ax)
+
+
+def rasterize_meshes(verts_ndc, faces, H, W):
+    """rasterize_meshes.cu CheckPixelInsideFace with blur_radius 0, faces_per_pixel 1, perspective_correct True,
+    clip_barycentric_coords False, cull_backfaces False.  verts_ndc [N,V,3] float32 (x_ndc, y_ndc, z_view), faces [F,3].
+    Returns pix_to_face [N,H,W,1] int64 (packed n*F + f, -1), bary [N,H,W,1,3], zbuf [N,H,W,1] (both -1 padded)."""
+    v = np.asarray(verts_ndc, np.float32); faces = np.asarray(faces, np.int64)
+    N, F = v.shape[0], faces.shape[0]
+    xs, ys = pixel_centres_ndc(H, W)
+    p2f = -np.ones((N, H, W, 1), np.int64); bary = -np.ones((N, H, W, 1, 3), np.float32); zbuf = -np.ones((N, H, W, 1), np.float32)
+    best = np.full((N, H, W), np.inf, np.float32)
+    f32 = np.float32
+    for n in range(N):
+        for f in range(F):
+            a, b, c = v[n, faces[f, 0]], v[n, faces[f, 1]], v[n, faces[f, 2]]
+            if max(a[2], b[2], c[2]) < 0:
+                continue
+            area = _edge(a[0], a[1], b[0], b[1], c[0], c[1])            # EdgeFunctionForward(v0, v1, v2)
+            if -K_EPS <= area <= K_EPS:
+                continue
+            xmin, xmax = min(a[0], b[0], c[0]), max(a[0], b[0], c[0])
+            ymin, ymax = min(a[1], b[1], c[1]), max(a[1], b[1], c[1])
+            cols = np.nonzero((xs >= xmin) & (xs <= xmax))[0]
+            rows = np.nonzero((ys >= ymin) & (ys <= ymax))[0]
+            if cols.size == 0 or rows.size == 0:
+                continue
+            px = xs[cols][None, :].astype(f32); py = ys[rows][:, None].astype(f32)
+            den = f32(_edge(c[0], c[1], a[0], a[1], b[0], b[1]) + K_EPS)                          # BarycentricCoordsForward
+            w0 = (_edge(px, py, b[0], b[1], c[0], c[1]) / den).astype(f32)
+            w1 = (_edge(px, py, c[0], c[1], a[0], a[1]) / den).astype(f32)
+            w2 = (_edge(px, py, a[0], a[1], b[0], b[1]) / den).astype(f32)
+            t0, t1, t2 = (w0 * b[2] * c[2]).astype(f32), (a[2] * w1 * c[2]).astype(f32), (a[2] * b[2] * w2).astype(f32)
+            dn = np.maximum((t0 + t1 + t2).astype(f32), K_EPS)                                    # BarycentricPerspectiveCorrectionForward
+            b0, b1, b2 = (t0 / dn).astype(f32), (t1 / dn).astype(f32), (t2 / dn).astype(f32)
+            pz = (b0 * a[2] + b1 * b[2] + b2 * c[2]).astype(f32)
+            inside = (b0 > 0) & (b1 > 0) & (b2 > 0) & (pz >= 0)
+            rr, cc = np.nonzero(inside)
+            for i, j in zip(rr, cc):
+                r, cpx = rows[i], cols[j]
+                if pz[i, j] < best[n, r, cpx]:
+                    best[n, r, cpx] = pz[i, j]
+                    p2f[n, r, cpx, 0] = n * F + f
+                    bary[n, r, cpx, 0] = (b0[i, j], b1[i, j], b2[i, j]); zbuf[n, r, cpx, 0] = pz[i, j]
+    return p2f, bary, zbuf

@@ -1,0 +1,2 @@
+/* TEST INFRASTRUCTURE ONLY -- see cuda.h in this directory. */
+#include "cuda.h"

@@ -250,21 +250,19 @@ __global__ __launch_bounds__(256) void mc_vertex_kernel(const float* __restrict_
     const int j = (int)(row - (int64_t)i * d.NY);
     const float v0 = sdf[c];
     const float vn = sdf[c + (dir == 0 ? strideX : dir == 1 ? strideY : 1)];
-    float x, y, z;
-    {
-#pragma clang fp contract(off)   // keep (a*b)+c unfused: vertex coordinates are then bit-equal to the C oracle
-    const float fX = (float)i, fY = (float)j, fZ = (float)k;
+    // Lattice coordinate of the crossing as CudaKernels.cu:363-365 writes it, fX + (offset + t * dir): the products are exact
+    // (dir is 0 or +-1), so they are folded here.  The scaling v*step+min of d_scale_vertices (:517-519) is ONE fused
+    // multiply-add, as nvcc's default -fmad=true compiles it: bit-equal to the reference's kernels built that way
+    // (oracle/_ref/libmc_ref_fma.so, tests/test_mc_reference_pin.py).
+    float x = (float)i, y = (float)j, z = (float)k;
     if (dir == 0) {          // cube edge 0: v0 -> v1, direction +x
-      const float t = edge_offset(v0, vn, iso);
-      x = (fX + (0.0f + t * 1.0f)) * sx + ox; y = (fY + (0.0f + t * 0.0f)) * sy + oy; z = (fZ + (0.0f + t * 0.0f)) * sz + oz;
+      x = x + (0.0f + edge_offset(v0, vn, iso));
     } else if (dir == 1) {   // cube edge 3: v3 -> v0, direction -y, starting at (0,1,0)
-      const float t = edge_offset(vn, v0, iso);
-      x = (fX + (0.0f + t * 0.0f)) * sx + ox; y = (fY + (1.0f + t * -1.0f)) * sy + oy; z = (fZ + (0.0f + t * 0.0f)) * sz + oz;
+      y = y + (1.0f + -edge_offset(vn, v0, iso));
     } else {                 // cube edge 8: v0 -> v4, direction +z
-      const float t = edge_offset(v0, vn, iso);
-      x = (fX + (0.0f + t * 0.0f)) * sx + ox; y = (fY + (0.0f + t * 0.0f)) * sy + oy; z = (fZ + (0.0f + t * 1.0f)) * sz + oz;
+      z = z + (0.0f + edge_offset(v0, vn, iso));
     }
-    }
+    x = __builtin_fmaf(x, sx, ox); y = __builtin_fmaf(y, sy, oy); z = __builtin_fmaf(z, sz, oz);
     verts[vid * 3 + 0] = x; verts[vid * 3 + 1] = y; verts[vid * 3 + 2] = z;
   }
 }

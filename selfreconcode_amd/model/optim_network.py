@@ -120,6 +120,58 @@ class OptimNetwork(nn.Module):
         verts, faces = out
         return verts, faces
 
+    # ------------------------------------------------------------------ per-pixel rendering (network.py:304-372, `infer`)
+    def render_frames(self, frame_ids, ratio, TmpVs=None, Tmpfs=None, chunk=20000, dthreshold=1.e-4, times=30, with_normals=True):
+        """Colour (and deformed-normal) images of the current model for `frame_ids` -- the colour pass of the reference's
+        `OptimNetwork.infer` (network.py:340-372): rasterise the deformed template, take every covered pixel's canonical seed
+        (FindSurfacePs), refine it on its ray with the looser inference tolerances (dthreshold 1e-4, 30 steps, chunks of rays),
+        then normal -> canonical view direction -> render MLP.  Returns dict(img [N,H,W,3] in [-1,1] (background 1), mask [N,H,W]
+        (rasterised silhouette), normal [N,H,W,3] in the image convention the normal loss reads (network.py:626-631: world normal
+        = R [diag(-1,1,-1)] n_img; background 0), converged [N,H,W] bool)."""
+        device = frame_ids.device
+        N = frame_ids.numel()
+        if TmpVs is None:
+            if self.TmpVs is None:
+                self.TmpVs, self.Tmpfs = self.discretizeSDF(ratio, None, -self.sdfShrinkRadius)
+                self.TmpVs.requires_grad = True
+                self.TmpOptimizer = torch.optim.SGD([self.TmpVs], lr=0.05, momentum=0.9)
+            TmpVs, Tmpfs = self.TmpVs.detach(), self.Tmpfs
+        cameras, H, W = self._cameras(N, device)
+        if self.angThred is None:
+            self.angThred = cameras.angThreshold(0.5)
+        with torch.no_grad():
+            poses, trans, d_cond, rendcond = [t.detach() for t in self.dataset.get_grad_parameters(frame_ids, device)]
+            defconds = [d_cond, [poses, trans]]
+            defTmpVs = self.deformer(TmpVs[None, :, :].expand(N, -1, 3), defconds, ratio=ratio)
+            pix, z = cameras.project(defTmpVs)
+            frags = rasterize_mesh(pix, z, Tmpfs, H, W)
+            batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(TmpVs, Tmpfs, frags)
+            rays = cameras.view_rays(torch.stack([col_inds, row_inds, torch.ones_like(col_inds)], dim=-1).float())
+            cam_pos = cameras.cam_pos().detach()
+            mask = (frags.pix_to_face[..., 0] >= 0).float()
+        img = torch.ones(N, H, W, 3, device=device)
+        nimg = torch.zeros(N, H, W, 3, device=device)
+        okimg = torch.zeros(N, H, W, dtype=torch.bool, device=device)
+        flipRt = (cameras.R[0].detach() @ torch.tensor([[-1., 0., 0.], [0., 1., 0.], [0., 0., -1.]], device=device)).t()
+        for rays_, ps_, bi_, r_, c_ in zip(*[torch.split(t, chunk) for t in (rays, initTmpPs, batch_inds, row_inds, col_inds)]):
+            ps_, check = OptimizeSurfacePs(cam_pos, rays_, ps_.clone(), bi_, self.sdf, ratio, self.deformer, defconds, dthreshold=dthreshold,
+                                           athreshold=self.angThred, w1=3.05, w2=1., times=times)
+            ps_.requires_grad = True
+            sdfs = self.sdf(ps_, ratio)
+            with mlp_engine.input_grads_only():
+                nx_raw = torch.autograd.grad(sdfs, ps_, torch.ones_like(sdfs), retain_graph=False, create_graph=False)[0]
+            nx = nx_raw / nx_raw.norm(dim=1, keepdim=True)
+            jac = {}
+            crays, defVs = U.compute_cardinal_rays(self.deformer, ps_, rays_, defconds, bi_, ratio, 'test', cache=jac)
+            with torch.no_grad():
+                cols = U.compute_netRender_color(self.netRender, ps_, defVs, nx, crays, self.sdf.rendcond, rendcond[bi_], ratio)
+                img[bi_, r_, c_] = cols
+                okimg[bi_, r_, c_] = check
+                if with_normals:
+                    dn, _ = U.compute_deformed_normals(self.sdf, self.deformer, ps_, defconds, bi_, ratio, 'test', cache=jac, onx=nx_raw)
+                    nimg[bi_, r_, c_] = dn @ flipRt.t()
+        return {'img': img, 'mask': mask, 'normal': nimg, 'converged': okimg}
+
     def _cameras(self, N, device):
         # fixed cameras (no learnable parameter) are built once: quaternion -> R and friends are ~40 tiny launches per call
         params = getattr(self.dataset, 'camera_params', None)

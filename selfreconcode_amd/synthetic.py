@@ -207,10 +207,25 @@ class SyntheticSequence:
                 masks.append(net._silhouette(dv, cameras, H, W, net.point_radius)[0] > 0.5)
             self._masks = torch.stack(masks)
 
+    def attach_rendered_observations(self, net, ratio, frames_per_call=4):
+        """Observations that the scene itself explains: colour, normal and silhouette images of EVERY frame rendered from the
+        model as it is now (OptimNetwork.render_frames = the colour pass of the reference's `infer`, network.py:340-372).
+        With them the colour / normal / mask terms sit at their optimum for the current weights, which is where a real
+        sequence spends almost all of its ~10^5 iterations; uniform-noise targets (the default of `batch`) keep those terms at
+        O(1) with gradients that never average out."""
+        imgs, normals, masks = [], [], []
+        for f0 in range(0, self.frame_num, frames_per_call):
+            fids = torch.arange(f0, min(f0 + frames_per_call, self.frame_num), device=self.device)
+            out = net.render_frames(fids, ratio)
+            imgs.append(out['img']); normals.append(out['normal']); masks.append(out['mask'] > 0.5)
+        self._imgs, self._normals, self._masks = torch.cat(imgs), torch.cat(normals), torch.cat(masks)
+
     def batch(self, frame_ids):
         """Synthetic observations: an elliptic ground-truth silhouette around the projected body and uniform-noise
         colour / normal images of the right shape."""
         N, H, W, dev = len(frame_ids), self.H, self.W, self.device
+        if getattr(self, "_imgs", None) is not None:           # rendered from the scene itself, see attach_rendered_observations
+            return {'img': self._imgs[frame_ids], 'mask': self._masks[frame_ids].float(), 'normal': self._normals[frame_ids]}
         g = torch.Generator(device=dev); g.manual_seed(1234 + int(frame_ids[0]))
         if getattr(self, "_masks", None) is not None:          # self-consistent observations, see attach_consistent_masks
             return {'img': torch.rand((N, H, W, 3), device=dev, generator=g) * 2 - 1, 'mask': self._masks[frame_ids].float(),
@@ -231,6 +246,11 @@ class SyntheticSequence:
 
 COARSE_RESOLUTIONS = [(14 + 1, 20 + 1, 8 + 1), (28 + 1, 40 + 1, 16 + 1), (56 + 1, 80 + 1, 32 + 1), (112 + 1, 160 + 1, 64 + 1),
                       (224 + 1, 320 + 1, 128 + 1)]                                    # train.py:29-35 (W,H,D)
+MEDIUM_RESOLUTIONS = [(18 + 1, 24 + 1, 12 + 1), (36 + 1, 48 + 1, 24 + 1), (72 + 1, 96 + 1, 48 + 1), (144 + 1, 192 + 1, 96 + 1),
+                      (288 + 1, 384 + 1, 192 + 1)]                                    # train.py:37-43
+FINE_RESOLUTIONS = [(20 + 1, 26 + 1, 14 + 1), (40 + 1, 52 + 1, 28 + 1), (80 + 1, 104 + 1, 56 + 1), (160 + 1, 208 + 1, 112 + 1),
+                    (320 + 1, 416 + 1, 224 + 1)]                                      # train.py:45-51
+STAGE_RESOLUTIONS = {'coarse': COARSE_RESOLUTIONS, 'medium': MEDIUM_RESOLUTIONS, 'fine': FINE_RESOLUTIONS}
 
 
 def build_synthetic_scene(device="cuda:0", frame_num=64, H=540, W=540, stage="coarse", resolutions=None, lbs_volume_shape=(65, 225, 129),
@@ -255,7 +275,7 @@ def build_synthetic_scene(device="cuda:0", frame_num=64, H=540, W=540, stage="co
     deformer = CompositeDeformer([tr, skin]).to(device)
     rend = RenderingNetwork_view_norm(conf.get_int('render_net.condlen'), 'idr', 9, 3, [512, 512, 512, 512], True,
                                       multires_n=conf.get_int('render_net.multires_n'), multires_v=conf.get_int('render_net.multires_v')).to(device)
-    engine = Seg3dLossless(query_func=None, b_min=LBS_BMIN, b_max=LBS_BMAX, resolutions=resolutions or COARSE_RESOLUTIONS,
+    engine = Seg3dLossless(query_func=None, b_min=LBS_BMIN, b_max=LBS_BMAX, resolutions=resolutions or STAGE_RESOLUTIONS[stage],
                            align_corners=False, balance_value=0.0).to(device)
     net = OptimNetwork(sdf, deformer, engine, None, rend, conf=conf.get_config('loss_' + stage)).to(device)
     net.remesh_intersect = conf.get_int(f'train.{stage}.point_render.remesh_intersect')

@@ -1,0 +1,85 @@
+"""Marching cubes pinned to the reference: the reference's OWN kernels (MCGpu/CudaKernels.cu:304-523 + class MCGpu),
+compiled for the host by oracle/Makefile (CUDA names from oracle/ref_mc/shim/cuda.h, threads run one after the other),
+against the C restatement oracle/mc_oracle.c and -- under -m gpu -- against the HIP kernels.
+
+What the comparison says (asserted below):
+  * face topology (after ordering vertices by lattice-edge key and sorting face rows) is identical in both builds of the
+    reference (with / without mul+add contraction) and equal to the restatement and to the HIP kernels;
+  * vertex coordinates are bit-equal to the CONTRACTED build (nvcc's default -fmad=true; the only contraction that
+    changes a bit is the v*step+min of d_scale_vertices) and one rounding of the product v*step (< 2^-22 here) away from the uncontracted one.
+The committed fixture tests/golden/mc_ref.npz (made by oracle/gen_mc_ref_golden.py from the contracted build) keeps the
+pin in force where neither /root/reference nor the prebuilt oracle/_ref files exist."""
+import os
+import numpy as np
+import pytest
+import torch
+from oracle import mc as mco
+from oracle import fixtures as fx
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mc_ref.npz")
+STEP, ORG = (0.1, 0.11, 0.09), (-1.0, -1.2, -0.7)
+
+
+def field(shape, kind, seed=5):
+    x, y, z = np.meshgrid(*[np.linspace(-1, 1, s) for s in shape], indexing='ij')
+    if kind == "sphere":
+        return (np.sqrt(x * x + 0.8 * y * y + z * z) - 0.63).astype(np.float32)
+    if kind == "two_blobs":
+        return (np.minimum(np.sqrt((x - .3) ** 2 + y * y + z * z) - .35, np.sqrt((x + .35) ** 2 + (y - .1) ** 2 + z * z) - .3)).astype(np.float32)
+    if kind == "open":                       # surface leaves the volume: faces with -1 corners on the far faces (i = NX-1 guard)
+        return (x + 0.3 * y - 0.2 * z + 0.05).astype(np.float32)
+    noise = fx.det_array(shape, seed, 1.0)   # rough field: many of the 256 cases, still below the reference's 5 % scratch
+    return (np.sqrt(x * x + y * y + z * z) - 0.6 + (0.12 if kind == "noisy" else 0.03) * noise).astype(np.float32)
+
+
+CASES = [((20, 24, 16), "sphere"), ((33, 17, 29), "two_blobs"), ((24, 24, 24), "noisy"), ((18, 22, 14), "open"), ((64, 80, 48), "noisy_lo")]
+needs_ref = pytest.mark.skipif(not mco.reference_available(), reason="neither /root/reference nor prebuilt oracle/_ref present")
+
+
+@needs_ref
+@pytest.mark.parametrize("shape,kind", CASES)
+def test_restatement_equals_reference_kernels(shape, kind):
+    s = field(shape, kind)
+    vo, ko, fo = mco.canonical(*mco.marching_cubes(s, STEP, ORG, 0.0))
+    vf, kf, ff = mco.canonical(*mco.reference_marching_cubes(s, STEP, ORG, 0.0, "fma"))
+    vn, kn, fn = mco.canonical(*mco.reference_marching_cubes(s, STEP, ORG, 0.0, "nofma"))
+    assert np.array_equal(kf, kn) and np.array_equal(ff, fn)          # topology does not depend on the contraction mode
+    assert np.array_equal(ko, kf) and np.array_equal(fo, ff)          # restatement == reference: vertex set and faces
+    assert np.array_equal(vo, vf)                                     # coordinates: bit-equal to the contracted (nvcc default) build
+    assert np.abs(vo - vn).max() <= 2.0 ** -22                        # uncontracted build: one rounding of the product (|v*step| < 4) apart
+    if kind == "open":
+        assert (fo < 0).any()
+    else:
+        assert fo.min() >= 0
+
+
+@needs_ref
+def test_iso_value_and_unit_steps():
+    s = field((28, 20, 24), "two_blobs")
+    for iso in (0.02, -0.05):
+        a = mco.canonical(*mco.marching_cubes(s, (1., 1., 1.), (0., 0., 0.), iso))
+        b = mco.canonical(*mco.reference_marching_cubes(s, (1., 1., 1.), (0., 0., 0.), iso, "fma"))
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+def test_restatement_equals_committed_reference_fixture():
+    g = np.load(GOLDEN)
+    for n, (shape, kind) in enumerate(CASES[:4]):
+        v, k, f = mco.canonical(*mco.marching_cubes(field(shape, kind), STEP, ORG, 0.0))
+        assert np.array_equal(v, g[f"v{n}"]) and np.array_equal(k, g[f"k{n}"]) and np.array_equal(f, g[f"f{n}"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,kind", CASES + [((129, 129, 129), "sphere"), ((160, 96, 128), "noisy_lo")])
+def test_hip_kernels_equal_reference_kernels(shape, kind):
+    if not mco.reference_available():
+        pytest.skip("prebuilt oracle/_ref not shipped")
+    from selfreconcode_amd.ext import MCGpu
+    s = field(shape, kind)
+    vf, kf, ff = mco.canonical(*mco.reference_marching_cubes(s, STEP, ORG, 0.0, "fma"))
+    verts, faces = MCGpu.mc_gpu(torch.from_numpy(s).to("cuda:0"), *STEP, *ORG, 0.0)
+    v, f = verts.cpu().numpy(), faces.cpu().numpy()
+    assert v.shape == vf.shape and f.shape == ff.shape
+    assert np.array_equal(v, vf)                                       # the HIP output is already in lattice-edge-key order
+    assert np.array_equal(f[np.lexsort((f[:, 2], f[:, 1], f[:, 0]))], ff)

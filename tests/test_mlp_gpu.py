@@ -208,3 +208,55 @@ def test_gemm_kernels_ragged_shapes_vs_float64(M, N, K):
     torch.testing.assert_close(dW[:, :K].cpu().double(), Z[:, :N].double().t() @ A[:, :K].double(), rtol=2e-5, atol=2e-5 * max(1.0, M ** 0.5))
     torch.testing.assert_close(db.cpu().double(), Z[:, :N].double().sum(0), rtol=2e-5, atol=2e-5 * max(1.0, M ** 0.5))
     assert torch.isfinite(dW).all()                                # padding columns [K, pad4(K)) are written as zeros
+
+
+def test_pe_embed_kernel_vs_reference_golden(golden):
+    """a1: the fused embed kernel itself against the reference's Embedder run (tests/golden/pe.npz): ratio None (all ones),
+    annealed 0.35 / 1.0 and the <= 0 switch (all PE weights zero, used by initializeTmpSDF with ratio -1)."""
+    from selfreconcode_amd.model.Embedder import embed_rows, get_embedder
+    from selfreconcode_amd.utils.utils import resolve_band_weights, annealing_weights
+    g = golden("pe")
+    x = g["x"].to(DEV)
+    for tag, ratio in (("none", None), ("r035", 0.35), ("r1", 1.0), ("neg", -1.0)):
+        out = embed_rows(x, 6, resolve_band_weights(6, ratio))
+        assert out.shape == (16, 40) and float(out[:, 39].abs().max()) == 0.0            # pad column is zero
+        close(out[:, :39], g[tag], 1e-6, 1e-6)
+    close(torch.tensor(annealing_weights(6, 0.35)), g["aw_035"], 1e-7, 1e-7)
+    close(torch.tensor(annealing_weights(4, 0.7)), g["aw_07_4"], 1e-7, 1e-7)
+    embed, dim = get_embedder(6)                                                         # API mirror (Embedder.py:44-54)
+    assert dim == 39
+    close(embed(x, annealing_weights(6, 0.35)), g["r035"], 1e-6, 1e-6)
+    # first- and second-order input derivatives of the embed Function against autograd of the oracle's closed form
+    xg = x.clone().requires_grad_(True)
+    w = fx.det_tensor((16, 39), 77, 1.0).to(DEV)
+    gx = torch.autograd.grad((embed_rows(xg, 6, annealing_weights(6, 0.8))[:, :39] * w).sum(), xg, create_graph=True)[0]
+    g2 = torch.autograd.grad((gx * gx).sum(), xg)[0]
+    xo = g["x"].clone().requires_grad_(True)
+    go = torch.autograd.grad((orc.pe_embed(xo, 6, annealing_weights(6, 0.8)) * w.cpu()).sum(), xo, create_graph=True)[0]
+    g2o = torch.autograd.grad((go * go).sum(), xo)[0]
+    close(gx, go, 1e-5, 1e-5); close(g2, g2o, 1e-4, 1e-3)
+
+
+def test_sdf_forward_backward_at_96k_rows_vs_fp64():
+    """Value check (not a property check) on the paths only large batches reach: 128x128 NT tiles, several tiles per CU,
+    weight-gradient GEMM with split-R > 1.  98 304 rows, full 257-wide output, against the CPU oracle in float64."""
+    P = 98304
+    net = _sdf(77)
+    sd64 = {k: v.double().requires_grad_(True) for k, v in fx.det_params(fx.SDF_SPEC, 77).items()}
+    x = fx.det_tensor((P, 3), 4242, 0.9)
+    go = fx.det_tensor((P, 257), 4243, 1.0) / P
+    xg = x.to(DEV).requires_grad_(True)
+    y = net(xg, 1.0)
+    l = (torch.cat([y, net.rendcond], 1) * go.to(DEV)).sum()
+    names = ["lin0.weight_v", "lin1.weight_v", "lin3.weight_g", "lin4.weight_v", "lin4.bias", "lin8.weight_v", "lin8.bias"]
+    ours = torch.autograd.grad(l, [xg] + [dict(net.named_parameters())[n] for n in names])
+    xo = x.double().requires_grad_(True)
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    yo, rc = orc.sdf_forward(sd64, xo, 1.0)
+    lo = (torch.cat([yo, rc], 1) * go.double()).sum()
+    ref = torch.autograd.grad(lo, [xo] + [sd64[n] for n in names])
+    close(y, yo.float(), 2e-5, 2e-6); close(net.rendcond, rc.float(), 2e-5, 2e-6)
+    close(ours[0], ref[0].float(), 1e-4, 1e-5 / P)
+    for n, a, b in zip(names, ours[1:], ref[1:]):
+        # sums over 98k rows: fp32 accumulation (fixed slab order) against float64
+        torch.testing.assert_close(a.cpu(), b.float(), rtol=2e-4, atol=2e-5 * max(1e-3, float(b.abs().max())), msg=lambda m, n=n: n + ": " + m)
