@@ -125,6 +125,23 @@ typedef struct {
 } sr_gemm_args;
 int sr_mlp_gemm_nt(const sr_gemm_args* host_args, void* stream);
 
+/* Persistent layer chain: up to SR_CHAIN_MAX_LAYERS consecutive layer GEMMs of one or two independent networks in ONE
+ * launch, on a row count read from device memory: rows = *m_dev * m_mul (every g[l][p].M is ignored; g[l][p].group must
+ * equal m_mul).  Layer l+1 starts after a device-wide barrier behind layer l, so g[l+1][p].A may be g[l][p].C.
+ * barrier: one uint32 of device scratch (zeroed by the call); error: int32 device flag, set to 1 if the barrier had to
+ * give up (the grid -- 2 workgroups per CU -- must be resident at once), never cleared by the call.
+ * This is the MLP half of the reference's utils/FindSurfacePs.py:129-162 loop body in two launches per Newton step
+ * (forward chain, reverse chain) whatever the number of live rays is. */
+#define SR_CHAIN_MAX_LAYERS 10
+typedef struct {
+  int32_t nlayers;
+  int32_t nprob[SR_CHAIN_MAX_LAYERS];
+  sr_gemm_args g[SR_CHAIN_MAX_LAYERS][2];
+  const int32_t* m_dev; int32_t m_mul;
+  uint32_t* barrier; int32_t* error;
+} sr_chain_args;
+int sr_mlp_chain(const sr_chain_args* host_args, void* stream);
+
 /* Weight gradient: dW[N, lddw] (+)= sum_r Z[r, 0:N]^T A[r, 0:K], all rows (primal and tangent).
  * Split over r into `splits` slabs in `partial` (>= splits*N*lddw floats, see _workspace_floats),
  * reduced in a fixed order (deterministic).  accumulate != 0 adds into dW. */
@@ -223,6 +240,42 @@ typedef struct {
 int sr_newton_prepare(const sr_newton2_args* host_args, void* stream);
 int sr_newton_apply(const sr_newton2_args* host_args, void* stream);
 
+/* ---------------------------------------------------------------- device-driven refiner (a12; the `sr_trace_newton` of SURVEY 8(b))
+ * The whole of utils/FindSurfacePs.py::OptimizeSurfacePs (:114-163) for P rays as a fixed sequence of launches whose row
+ * count lives in device memory: `live[k]` = unfinished rays entering phase k (live[0] = P).  The queue of unfinished rays
+ * (x, v, frame, orig: two copies, phase parity selects) is compacted by wave ballots at the end of every phase, so finished
+ * rays leave the layer GEMMs immediately and the host never learns a count.  Per phase the caller issues
+ *   sr_refine_embed -> sr_mlp_chain(forward, m_dev = live + k) -> sr_refine_mid
+ *   [-> sr_mlp_chain(reverse) -> sr_refine_finish   for the update phases 1..times]
+ * phase 0 (mid mode 0): initial test; phases 1..times (mode 1): test of the current points + Newton update of the failing
+ * ones; phase times+1 (mode 2): test of the last update.  p_out / conv_out are indexed by the rays' original position.
+ * The layer chains read a0 / a0d (first-layer inputs, written by _embed) and leave f in sdf_out[:,0], the deformation
+ * offset in def_out[:,0:3]; the reverse chains start from `unit` rows (1,0,0,0) (SDF) and `t` rows (deformer) and leave
+ * the input cotangents in a0bar (+ skipbar: the skip-concat part, n_skip columns) and a0dbar. */
+typedef struct {
+  int32_t P, times;
+  const float* p0; const float* rays; const int64_t* batch_inds;   /* [P,3], [P,3], [P] inputs (read by _init) */
+  const float* cam;                                                /* [3] camera centre (device) */
+  int32_t L_sdf; const float* w_sdf; int32_t L_def; const float* w_def;   /* PE bands + per-band weights (2L floats each) */
+  const float* conds; int64_t ld_conds; int32_t E;                 /* per-frame deformation codes [nframes, E] */
+  const float* A; const float* trans; int32_t nframes;             /* posed transforms [nframes,24,12], translations [nframes,3] */
+  const float* vol; int32_t D, H, W; float bmin[3], bmax[3];       /* channel-last skinning-weight volume + its box */
+  float dthreshold, athreshold, w1, w2;
+  int32_t* live;                                                   /* [times + 3] */
+  float* x[2]; float* v[2]; int32_t* frame[2]; int32_t* orig[2];   /* the queue: [P,3], [P,3], [P], [P] each */
+  float* unit;                                                     /* [P,4] rows (1,0,0,0), written by _init */
+  float* a0; int64_t ld_a0; float* a0d; int64_t ld_a0d;
+  const float* sdf_out; int64_t ld_sdf; const float* def_out; int64_t ld_def;
+  uint8_t* conv; float* t; float* s;                               /* [P], [P,4], [P] */
+  const float* a0bar; int64_t ld_a0bar; const float* skipbar; int64_t ld_skipbar; int32_t n_skip;
+  const float* a0dbar; int64_t ld_a0dbar;
+  float* p_out; uint8_t* conv_out;                                 /* [P,3], [P] */
+} sr_refine_args;
+int sr_refine_init(const sr_refine_args* host_args, void* stream);
+int sr_refine_embed(const sr_refine_args* host_args, int32_t phase, void* stream);
+int sr_refine_mid(const sr_refine_args* host_args, int32_t phase, int32_t mode, void* stream);
+int sr_refine_finish(const sr_refine_args* host_args, int32_t phase, void* stream);
+
 
 /* ---------------------------------------------------------------- MCGpu (a17)
  * Replaces MCGpu/MCGpu.cpp:20-56 mc_gpu -> MCGpu::init/MC/scaleVertices (CudaKernels.cu:524-639) and
@@ -245,15 +298,8 @@ int sr_mc_emit(const float* sdf, int32_t nx, int32_t ny, int32_t nz, float iso, 
 /* ---------------------------------------------------------------- small per-element ops
  * sr_svd3x3: batched 3x3 SVD on device, A = U diag(S) V^T, S descending -- replaces
  *   `torch.svd(Jacobs.cpu())` of the deformation regulariser (model/network.py:576).  A,U,V [n,3,3], S [n,3].
- * sr_splat_fwd/bwd: soft point-splat silhouette, the stand-in for the pytorch3d PointsRasterizer +
- *   AlphaCompositor call of model/network.py:497 (third-party code, parity unpinned -- SURVEY.md 8(c)):
- *   logT[img,y,x] += log(1 - a), a = 1 - |pixel - p|^2 / r^2 for pixels within r (pixels); mask = 1 - exp(logT).
- *   pix [nimg, pts_per_img, 2] (x=col, y=row); vis [nimg*pts_per_img] u8 nullable; logT zero-filled by the caller. */
+ */
 int sr_svd3x3(const float* A, int64_t n, float* U, float* S, float* V, void* stream);
-int sr_splat_fwd(const float* pix, const uint8_t* vis, int64_t nimg, int64_t pts_per_img, int32_t H, int32_t W, float radius_px,
-                 float* logT, void* stream);
-int sr_splat_bwd(const float* pix, const uint8_t* vis, int64_t nimg, int64_t pts_per_img, int32_t H, int32_t W, float radius_px,
-                 const float* logT, const float* gmask, float* gpix, void* stream);
 
 /* ---------------------------------------------------------------- interp2x_boundary3d (K10/K11)
  * Replaces MCAcc/cuda/interp2x_boundary3d.cpp:forward/backward -> interp2x_boundary3d_kernel.cu:11-151, 155-239
@@ -265,15 +311,29 @@ int sr_interp2x3d_fwd_f64(const double* in, int64_t BC, int32_t d, int32_t h, in
 int sr_interp2x3d_bwd_f32(const float* grad_out, int64_t BC, int32_t d, int32_t h, int32_t w, float* grad_in, void* stream);
 int sr_interp2x3d_bwd_f64(const double* grad_out, int64_t BC, int32_t d, int32_t h, int32_t w, double* grad_in, void* stream);
 
-/* Hard mesh rasteriser: stands where the reference calls pytorch3d's MeshRasterizer (model/network.py:492;
- * faces_per_pixel=1, blur 0, perspective-correct barycentrics, no culling) to seed its rays through FindSurfacePs.
- * pix [nimg,V,2] projected pixel coordinates (x = column, y = row; integer = pixel centre), z [nimg,V] camera depth,
- * faces [F,3] int64 shared by all images (rows containing -1 are skipped).  Outputs: pix_to_face [nimg,H,W] int64
- * (packed index img*F + f, -1 = background), bary [nimg,H,W,3] (-1 on background), zout [nimg,H,W] nullable.
- * zbuf_u64: scratch of nimg*H*W 8-byte words; pix_to_face and the (8-byte aligned) head of bary hold the large-triangle
- * queue until the last pass overwrites them.  Third-party behaviour, parity unpinned (no pytorch3d here). */
-int sr_raster_mesh(const float* pix, const float* z, const int64_t* faces, int64_t nimg, int64_t V, int64_t F, int32_t H, int32_t W,
-                   void* zbuf_u64, int64_t* pix_to_face, float* bary, float* zout, void* stream);
+/* ---------------------------------------------------------------- rasterisation either side of the refiner
+ * The reference calls pytorch3d 0.4.0 here (third-party CUDA, not in its repository; restated in oracle/raster_oracle.py,
+ * parity unpinned).  Both entry points work in pytorch3d's NDC frame: +x left, +y up, pixel (row, col) centred at
+ * (1 - (2 col + 1)/W, 1 - (2 row + 1)/H); xy_ndc [nimg, V, 2], z [nimg, V] = view-space depth.
+ *
+ * sr_points_silhouette_*: replaces PointsRasterizer(radius, points_per_pixel = K) + AlphaCompositor with one all-ones
+ *   feature as called at model/network.py:178-190,495-497 through PointsRendererWithFrags (model/CameraMine.py:285-305):
+ *   mask[img,row,col] = sum_k a_k prod_{j<k}(1 - a_j) over the K covering points nearest in z, a = 1 - dist2/radius^2
+ *   (dist2 < radius^2, NDC units; z < 0 skipped).  _bwd returns d(sum gmask * mask)/d xy_ndc (what pytorch3d's
+ *   rasterize_points backward propagates through `dists`).  `workspace` (256-byte aligned, _workspace_bytes) carries the
+ *   per-pixel transmittance and selection thresholds from _fwd to _bwd.
+ * sr_rasterize_meshes: replaces MeshRasterizer(blur_radius 0, faces_per_pixel 1, perspective_correct, no barycentric
+ *   clipping, no culling) of model/network.py:877-892,492: faces [F,3] int64 shared by all images (rows containing -1 are
+ *   skipped: MCGpu border faces) -> pix_to_face [nimg,H,W] int64 (packed img*F + f, -1 = background), bary [nimg,H,W,3]
+ *   (-1 on background), zout [nimg,H,W] nullable.  zbuf_u64: scratch of nimg*H*W 8-byte words; pix_to_face and the
+ *   (8-byte aligned) head of bary hold the large-face queue until the last pass overwrites them. */
+int64_t sr_points_silhouette_workspace_bytes(int64_t nimg, int64_t pts_per_img, int32_t H, int32_t W, float radius);
+int sr_points_silhouette_fwd(const float* xy_ndc, const float* z, int64_t nimg, int64_t pts_per_img, int32_t H, int32_t W, float radius,
+                             int32_t K, float* mask, void* workspace, void* stream);
+int sr_points_silhouette_bwd(const float* xy_ndc, const float* z, int64_t nimg, int64_t pts_per_img, int32_t H, int32_t W, float radius,
+                             const void* workspace, const float* gmask, float* gxy, void* stream);
+int sr_rasterize_meshes(const float* xy_ndc, const float* z, const int64_t* faces, int64_t nimg, int64_t V, int64_t F, int32_t H, int32_t W,
+                        void* zbuf_u64, int64_t* pix_to_face, float* bary, float* zout, void* stream);
 
 #ifdef __cplusplus
 }

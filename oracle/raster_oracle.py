@@ -130,6 +130,8 @@ def rasterize_meshes(verts_ndc, faces, H, W):
     f32 = np.float32
     for n in range(N):
         for f in range(F):
+            if faces[f].min() < 0:        # MCGpu leaves -1 where the owner cell of a vertex lies outside the volume (CudaKernels.cu:470):
+                continue                  # such faces cannot be rasterised (pytorch3d would index out of range); the product skips them too
             a, b, c = v[n, faces[f, 0]], v[n, faces[f, 1]], v[n, faces[f, 2]]
             if max(a[2], b[2], c[2]) < 0:
                 continue

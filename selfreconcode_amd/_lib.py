@@ -49,13 +49,38 @@ class SrNewton2Args(ctypes.Structure):
                 ("dthreshold", ctypes.c_float), ("athreshold", ctypes.c_float), ("w1", ctypes.c_float), ("w2", ctypes.c_float)]
 
 
+SR_CHAIN_MAX_LAYERS = 10
+
+
+class SrChainArgs(ctypes.Structure):
+    _fields_ = [("nlayers", ctypes.c_int32), ("nprob", ctypes.c_int32 * SR_CHAIN_MAX_LAYERS), ("g", (SrGemmArgs * 2) * SR_CHAIN_MAX_LAYERS),
+                ("m_dev", _vp), ("m_mul", ctypes.c_int32), ("barrier", _vp), ("error", _vp)]
+
+
+class SrRefineArgs(ctypes.Structure):
+    _f, _i32 = ctypes.c_float, ctypes.c_int32
+    _fields_ = [("P", _i32), ("times", _i32), ("p0", _vp), ("rays", _vp), ("batch_inds", _vp), ("cam", _vp),
+                ("L_sdf", _i32), ("w_sdf", _vp), ("L_def", _i32), ("w_def", _vp), ("conds", _vp), ("ld_conds", _i64), ("E", _i32),
+                ("A", _vp), ("trans", _vp), ("nframes", _i32), ("vol", _vp), ("D", _i32), ("H", _i32), ("W", _i32),
+                ("bmin", _f * 3), ("bmax", _f * 3), ("dthreshold", _f), ("athreshold", _f), ("w1", _f), ("w2", _f),
+                ("live", _vp), ("x", _vp * 2), ("v", _vp * 2), ("frame", _vp * 2), ("orig", _vp * 2), ("unit", _vp),
+                ("a0", _vp), ("ld_a0", _i64), ("a0d", _vp), ("ld_a0d", _i64), ("sdf_out", _vp), ("ld_sdf", _i64), ("def_out", _vp), ("ld_def", _i64),
+                ("conv", _vp), ("t", _vp), ("s", _vp), ("a0bar", _vp), ("ld_a0bar", _i64), ("skipbar", _vp), ("ld_skipbar", _i64), ("n_skip", _i32),
+                ("a0dbar", _vp), ("ld_a0dbar", _i64), ("p_out", _vp), ("conv_out", _vp)]
+
+
 class SrError(RuntimeError):
     pass
 
 
 _CODES = {-1: "SR_EINVAL (bad argument)", -2: "SR_ELAUNCH (kernel launch failed)", -3: "SR_ENOSPC (workspace too small)"}
 
-LIB = os.environ.get("SELFRECON_HIP_LIB", LIB)   # tuning hook: point at an experimental build of the same ABI
+if "SELFRECON_HIP_LIB" in os.environ:
+    LIB = os.environ["SELFRECON_HIP_LIB"]         # tuning hook: point at an experimental build of the same ABI
+else:
+    from .build import is_stale, build_lib
+    if is_stale():                                # sources changed since the .so was linked (or no .so yet): kernels and the ctypes
+        build_lib(verbose=False)                  # structs below must come from the same tree -- rebuild (hipcc) or fail loudly
 if not os.path.isfile(LIB):
     raise ImportError(f"{LIB} not found: run `python -m selfreconcode_amd.build` (hipcc --offload-arch=gfx950). "
                       "There is no CPU fallback for the HIP hot path.")
@@ -78,6 +103,11 @@ SIGNATURES = {
     "sr_gridsample3d_dbwd_f32": [_vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _vp, _vp],
     "sr_gridsample3d_dbwd_f64": [_vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _vp, _vp],
     "sr_mlp_gemm_nt": [_vp, _vp],
+    "sr_mlp_chain": [_vp, _vp],
+    "sr_refine_init": [_vp, _vp],
+    "sr_refine_embed": [_vp, ctypes.c_int32, _vp],
+    "sr_refine_mid": [_vp, ctypes.c_int32, ctypes.c_int32, _vp],
+    "sr_refine_finish": [_vp, ctypes.c_int32, _vp],
     "sr_mlp_gemm_tn_workspace_floats": [ctypes.c_int32, ctypes.c_int32, _i64, _vp],
     "sr_mlp_gemm_tn": [_vp, _vp],
     "sr_colsum_rows": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
@@ -92,17 +122,18 @@ SIGNATURES = {
     "sr_mc_count": [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp],
     "sr_mc_emit": [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp] + [ctypes.c_float] * 6 + [_vp, _vp, _vp],
     "sr_svd3x3": [_vp, _i64, _vp, _vp, _vp, _vp],
-    "sr_splat_fwd": [_vp, _vp, _i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp],
-    "sr_splat_bwd": [_vp, _vp, _i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp, _vp],
+    "sr_points_silhouette_workspace_bytes": [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float],
+    "sr_points_silhouette_fwd": [_vp, _vp, _i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_int32, _vp, _vp, _vp],
+    "sr_points_silhouette_bwd": [_vp, _vp, _i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp, _vp],
     "sr_interp2x3d_fwd_f32": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp],
     "sr_interp2x3d_fwd_f64": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp],
     "sr_interp2x3d_bwd_f32": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
     "sr_interp2x3d_bwd_f64": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
-    "sr_raster_mesh": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp],
+    "sr_rasterize_meshes": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp],
     "sr_pe_embed_bwd": [_vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _i64, _vp, _vp],
     "sr_pe_embed": [_vp, _i64, ctypes.c_int32, _vp, _vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _i64, _vp],
 }
-_RESTYPE = {"sr_mlp_gemm_tn_workspace_floats": _i64, "sr_mc_workspace_bytes": _i64}
+_RESTYPE = {"sr_mlp_gemm_tn_workspace_floats": _i64, "sr_mc_workspace_bytes": _i64, "sr_points_silhouette_workspace_bytes": _i64}
 
 _fn = {}
 for _name, _args in SIGNATURES.items():

@@ -26,7 +26,7 @@ def _digest():
     h = hashlib.sha256()
     for f in _sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(PKG, "..", "include", "selfrecon_hip.h")]:
         with open(f, "rb") as fh:
-            h.update(f.encode()); h.update(fh.read())
+            h.update(os.path.relpath(f, PKG).encode()); h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 

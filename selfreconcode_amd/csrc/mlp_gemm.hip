@@ -279,10 +279,11 @@ __device__ __forceinline__ void epilogue_interior_act(const sr_gemm_args& g, f32
 
 // ------------------------------------------------------------------------------------------------
 // C = epilogue(A[M,K] * B[N,K]^T)
+// One output tile (workgroup-wide).  `wg` is the linear tile index of this launch / layer; `smem` the workgroup's LDS
+// (Cfg::kLdsFloats floats).  Called once per workgroup by gemm_nt_kernel and in a loop by the persistent chain kernel.
 template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_kernel(sr_gemm_args g) {
+__device__ __forceinline__ void gemm_nt_tile(const sr_gemm_args& g, int wg, float* __restrict__ smem) {
   using C_ = Cfg<WM, WN, TM, TN>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   auto As = [&](int buf) -> float* { return smem + buf * (C_::BM * LDSP); };
   auto Bs = [&](int buf) -> float* { return smem + 2 * C_::BM * LDSP + buf * (C_::BN * LDSP); };
 
@@ -291,7 +292,6 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
   const int tiles_n = (g.N + g.naux_fwd + C_::BN - 1) / C_::BN;
   const int tiles_m = (g.M + C_::BM - 1) / C_::BM;
   const int nwg = tiles_m * tiles_n;
-  int wg = blockIdx.x;
   {
     const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, loc = wg / 8;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -404,12 +404,69 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
         default: epilogue_interior_act<WM, WN, TM, TN, 4, SR_EPI_BWD>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
       }
     }
-    return;
+  } else {
+    switch (g.group) {
+      case 1: epilogue<WM, WN, TM, TN, 1>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
+      case 2: epilogue<WM, WN, TM, TN, 2>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
+      default: epilogue<WM, WN, TM, TN, 4>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
+    }
   }
-  switch (g.group) {
-    case 1: epilogue<WM, WN, TM, TN, 1>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
-    case 2: epilogue<WM, WN, TM, TN, 2>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
-    default: epilogue<WM, WN, TM, TN, 4>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
+}
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_kernel(sr_gemm_args g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  gemm_nt_tile<WM, WN, TM, TN>(g, blockIdx.x, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent layer chain: ONE launch runs up to SR_CHAIN_MAX_LAYERS consecutive layers of one or two independent MLPs
+// (e.g. layer l of the SDF and of the deformation network side by side) on a row count that lives in DEVICE memory.
+// The workgroups of a resident grid (2 per CU) walk the tiles of a layer with a stride of the grid size and meet at a
+// device-wide barrier before the next layer reads what this one wrote.  Written for the ray refiner, whose batch shrinks
+// from step to step (the live count is produced by the compaction kernel of the previous step and never visits the host)
+// and whose ~6k rows make a layer too short to amortise a launch: 14 + 14 layer launches per Newton step become 2.
+__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t target, int32_t* error) {
+  __syncthreads();
+  bool ok = true;
+  if (threadIdx.x == 0) {
+    __threadfence();                                   // release: this workgroup's stores (made visible to thread 0 by the barrier above)
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    long long spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1ll << 24) || __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {   // a workgroup never arrived
+        __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                          // (grid not co-resident): give up
+        ok = false;
+        break;
+      }
+    }
+    __threadfence();                                   // acquire for the whole workgroup (through the barrier below)
+  }
+  ok = __syncthreads_and(ok);
+  return ok;
+}
+
+using ChainCfg = Cfg<2, 2, 1, 1>;      // 64x64 tiles: the refiner's few thousand rows give ~100 row panels
+__global__ __launch_bounds__(ChainCfg::kThreads) __attribute__((amdgpu_waves_per_eu(2))) void mlp_chain_kernel(sr_chain_args c) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int M = *c.m_dev * c.m_mul;
+  for (int l = 0; l < c.nlayers; ++l) {
+    int ntiles[2] = {0, 0};
+    if (M > 0) {
+      for (int p = 0; p < c.nprob[l]; ++p) {
+        const sr_gemm_args& g = c.g[l][p];
+        ntiles[p] = ((M + ChainCfg::BM - 1) / ChainCfg::BM) * ((g.N + (g.mode == SR_EPI_FWD ? g.naux_fwd : 0) + ChainCfg::BN - 1) / ChainCfg::BN);
+      }
+    }
+    for (int t = blockIdx.x; t < ntiles[0] + ntiles[1]; t += gridDim.x) {
+      const int p = t < ntiles[0] ? 0 : 1;
+      sr_gemm_args g = c.g[l][p];
+      g.M = M;
+      gemm_nt_tile<2, 2, 1, 1>(g, t - (p ? ntiles[0] : 0), smem);
+      __syncthreads();                                 // the next tile reuses the LDS image
+    }
+    if (l + 1 < c.nlayers && !grid_barrier(c.barrier, (uint32_t)(l + 1) * gridDim.x, c.error)) return;
   }
 }
 
@@ -678,6 +735,38 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
     }
   }
 #undef SR_NT_LAUNCH
+  return sr_launch_status();
+}
+
+static int chain_grid_size() {
+  static int grid = 0;
+  if (!grid) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mlp_chain_kernel, ChainCfg::kThreads, ChainCfg::kLdsFloats * sizeof(float)) != hipSuccess) return 0;
+    if (per_cu > 2) per_cu = 2;
+    grid = cus * per_cu;
+  }
+  return grid;
+}
+
+int sr_mlp_chain(const sr_chain_args* a, void* stream) {
+  if (!a || a->nlayers < 1 || a->nlayers > SR_CHAIN_MAX_LAYERS || !a->m_dev || !a->barrier || !a->error || a->m_mul < 1) return SR_EINVAL;
+  for (int l = 0; l < a->nlayers; ++l) {
+    if (a->nprob[l] < 1 || a->nprob[l] > 2) return SR_EINVAL;
+    for (int p = 0; p < a->nprob[l]; ++p) {
+      const sr_gemm_args& g = a->g[l][p];
+      if (!g.A || !g.B || !g.C || g.N <= 0 || g.K <= 0 || g.group != a->m_mul) return SR_EINVAL;
+      if ((g.lda & 3) || (g.ldb & 3) || (g.ldc & 3) || ((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || ((uintptr_t)g.C & 15)) return SR_EINVAL;
+      if (g.mode != SR_EPI_FWD && g.mode != SR_EPI_BWD) return SR_EINVAL;
+      if (g.mode == SR_EPI_BWD && g.naux_fwd != 0) return SR_EINVAL;
+      if ((g.mode == SR_EPI_BWD && g.act != SR_ACT_NONE && !g.aux) || (g.mode == SR_EPI_FWD && g.naux_fwd > 0 && !g.aux)) return SR_EINVAL;
+    }
+  }
+  const int grid = chain_grid_size();
+  if (grid <= 0) return SR_ELAUNCH;
+  if (hipMemsetAsync(a->barrier, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return SR_ELAUNCH;
+  hipLaunchKernelGGL(mlp_chain_kernel, dim3(grid), dim3(ChainCfg::kThreads), ChainCfg::kLdsFloats * sizeof(float), (hipStream_t)stream, *a);
   return sr_launch_status();
 }
 

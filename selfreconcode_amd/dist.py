@@ -34,47 +34,116 @@ def is_distributed():
 
 
 class GradBucket:
-    """All gradients of `tensors` as ONE contiguous fp32 buffer -> one collective per step.
+    """All gradients of `tensors` as contiguous fp32 buffers -> one collective per buffer.
     15.2 MB of MLP parameters + the dense per-frame learnables (poses, trans, codes: every row moves
-    through Adam's moments each step, so they are reduced densely)."""
+    through Adam's moments each step, so they are reduced densely).
 
-    def __init__(self, tensors):
+    `early`: the subset whose gradients are final after the outer `loss.backward()` (render network, render codes:
+    `propagateTmpPsGrad` does not touch them).  `start_early()` launches their all-reduce asynchronously so that it runs
+    under the implicit-gradient pass; `all_reduce_mean()` reduces the rest and waits for both."""
+
+    def __init__(self, tensors, early=()):
+        early_ids = self.early_ids = {id(t) for t in early}
         self.tensors = [t for t in tensors if t.requires_grad]
+        self.groups = [[t for t in self.tensors if id(t) in early_ids], [t for t in self.tensors if id(t) not in early_ids]]
         self.numel = sum(t.numel() for t in self.tensors)
-        self.flat = None
+        self.flat = [None, None]
+        self.views = [None, None]
+        self._pending = None
+
+    def sync_initial_state(self, extra=()):
+        """Rank 0's parameters (and `extra` tensors, e.g. buffers) to every rank: the frame-parallel scheme assumes bit-identical
+        replicas (the remesh and the template all-reduce depend on it) and must not rely on identical seeding."""
+        if not is_distributed():
+            return
+        with torch.no_grad():
+            for t in list(self.tensors) + list(extra):
+                dist.broadcast(t.data, src=0)
+
+    def _gather(self, g):
+        ts = self.groups[g]
+        if not ts:
+            return None
+        dev = ts[0].device
+        if self.flat[g] is None or self.flat[g].device != dev:
+            self.flat[g] = torch.zeros(sum(t.numel() for t in ts), dtype=torch.float32, device=dev)
+            self.views[g], off = [], 0
+            for t in ts:
+                n = t.numel()
+                self.views[g].append(self.flat[g][off:off + n].view_as(t))
+                off += n
+        have = [(v, t.grad) for v, t in zip(self.views[g], ts) if t.grad is not None]
+        if len(have) != len(ts):
+            self.flat[g].zero_()                           # parameters without a gradient on this rank contribute zeros
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [gr.to(torch.float32) if gr.dtype != torch.float32 else gr for _, gr in have])
+        return self.flat[g]
+
+    def _scatter(self, g):
+        ts = self.groups[g]
+        if not ts:
+            return
+        self.flat[g].div_(dist.get_world_size())
+        for t in ts:
+            if t.grad is None:
+                t.grad = torch.empty_like(t)
+        torch._foreach_copy_([t.grad for t in ts], self.views[g])
+
+    def start_early(self):
+        if not is_distributed() or not self.groups[0] or self._pending is not None:
+            return
+        flat = self._gather(0)
+        self._pending = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def all_reduce_mean(self):
-        """Gather (one multi-tensor copy) -> all-reduce -> scatter back (one multi-tensor copy): ~5 launches per step instead of
+        """Gather (one multi-tensor copy) -> all-reduce -> scatter back (one multi-tensor copy) per buffer: ~5 launches instead of
         two per parameter tensor (~260), which is what the weak-scaling efficiency pays for on top of the collective itself."""
         if not is_distributed() or not self.tensors:
             return
-        dev = self.tensors[0].device
-        if self.flat is None or self.flat.device != dev:
-            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-            self.views, off = [], 0
-            for t in self.tensors:
-                n = t.numel()
-                self.views.append(self.flat[off:off + n].view_as(t))
-                off += n
-        have = [(v, t.grad) for v, t in zip(self.views, self.tensors) if t.grad is not None]
-        if len(have) != len(self.tensors):
-            self.flat.zero_()                              # parameters without a gradient on this rank contribute zeros
-        if have:
-            torch._foreach_copy_([v for v, _ in have], [g.to(torch.float32) if g.dtype != torch.float32 else g for _, g in have])
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(dist.get_world_size())
-        for v, t in zip(self.views, self.tensors):
-            if t.grad is None:
-                t.grad = torch.empty_like(t)
-        torch._foreach_copy_([t.grad for t in self.tensors], self.views)
+        if self._pending is None and self.groups[0]:
+            self.start_early()
+        flat = self._gather(1)
+        if flat is not None:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            self._scatter(1)
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None
+            self._scatter(0)
 
 
 def all_reduce_mean_(tensor):
-    """In-place mean over ranks (used for the template-vertex gradient before its SGD step, caveat A)."""
-    if is_distributed() and tensor is not None:
+    """In-place mean over ranks (used for the template-vertex gradient before its SGD step, caveat A).  Every rank must call it
+    with a tensor of the same shape: a rank without a gradient passes zeros, never None (a skipped collective deadlocks the rest)."""
+    if is_distributed():
+        if tensor is None:
+            raise RuntimeError("all_reduce_mean_: tensor is None on this rank; pass zeros so that every rank joins the collective")
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
         tensor.div_(dist.get_world_size())
     return tensor
+
+
+def assert_same_across_ranks(value, what):
+    """Raises on every rank if the integer `value` differs between ranks (e.g. the template's vertex count after a remesh:
+    a 1-ulp divergence of the replicas changes it, and the template all-reduce would then hang or corrupt memory)."""
+    if not is_distributed():
+        return
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([value, -value], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if int(t[0]) != -int(t[1]):
+        raise RuntimeError(f"{what} differs between ranks (min {-int(t[1])}, max {int(t[0])}): replicas have diverged")
+
+
+def pooled_mean_weight(count, device):
+    """Factor that turns the mean of per-rank means into the mean over the points of ALL ranks for a term averaged over
+    `count` local points (SURVEY.md 8(e) caveat B): n_r * R / sum_r n_r, as a device scalar (no host sync)."""
+    if not is_distributed():
+        return None
+    t = torch.tensor([float(count)], dtype=torch.float32, device=device)
+    tot = t.clone()
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    return (t * dist.get_world_size() / tot.clamp(min=1.0)).squeeze(0)
 
 
 def shard_frames(global_frame_ids, rank, world):

@@ -111,8 +111,26 @@ class _GemmProfile:
         tf, n, us, fl = rate(alone)                                   # launches that had the GPU to themselves
         tf_all, n_all, us_all, _ = rate([True] * len(self.records))
         tf_big, n_big, _, _ = rate([a and r[3] >= 65536 for a, r in zip(alone, self.records)])
+        self._times = times
         return {"tflops": round(tf, 3), "launches": n, "avg_us": round(us, 3), "avg_flop": round(fl, 1), "tflops_large": round(tf_big, 3),
-                "launches_large": n_big, "tflops_all": round(tf_all, 3), "launches_all": n_all, "avg_us_all": round(us_all, 3)}
+                "launches_large": n_big, "tflops_all": round(tf_all, 3), "launches_all": n_all, "avg_us_all": round(us_all, 3),
+                "avg_flop_all": round(sum(r[2] for r in self.records) / max(n_all, 1), 1), "flops_total": float(sum(r[2] for r in self.records))}
+
+    def by_shape(self):
+        """Per (M, N, K, epilogue mode, overlap flag): launches, total FLOP, total event time, TFLOP/s -- the table that makes
+        the roofline figure reproducible next to the rocprof kernel trace (tools/summarize_profile.py joins the two)."""
+        if not self.records:
+            return []
+        times = getattr(self, "_times", None) or [r[0].elapsed_time(r[1]) for r in self.records]
+        acc = {}
+        for r, t in zip(self.records, times):
+            key = (r[3],) + tuple(r[5]) + (bool(r[4]),)
+            a = acc.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += r[2]; a[2] += t
+        rows = [{"M": k[0], "N": k[1], "K": k[2], "mode": k[3], "group": k[4], "overlap": k[5], "launches": v[0], "flop": v[1], "ms": round(v[2], 4),
+                 "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2) if v[2] > 0 else 0.0} for k, v in acc.items()]
+        rows.sort(key=lambda r: -r["ms"])
+        return rows
 
 
 PROFILE = _GemmProfile()
@@ -131,7 +149,7 @@ def _gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, group, act, mode, out_scale=
         e0.record()
         _lib.call("sr_mlp_gemm_nt", ctypes.byref(a), _lib.stream_of(C))
         e1.record()
-        PROFILE.records.append((e0, e1, 2.0 * M * N * K, M, PROFILE.overlap))
+        PROFILE.records.append((e0, e1, 2.0 * M * N * K, M, PROFILE.overlap, (N, K, mode, group)))
         return
     _lib.call("sr_mlp_gemm_nt", ctypes.byref(a), _lib.stream_of(C))
 
@@ -461,9 +479,12 @@ def _deferred_sink(W, b):
     return e["dW"], e["db"], accumulate
 
 
-def flush_param_grads():
+def flush_param_grads(only=None):
+    """`only`: ids of parameter tensors (weight_v / weight) whose layers are flushed now; the rest stays pending."""
     for e in list(_PACK_CACHE.values()):
         if not e.get("dirty"):
+            continue
+        if only is not None and id(e["src"][0]) not in only:
             continue
         dW = e["dW"]
         src = e["src"]

@@ -32,6 +32,17 @@ class RectifiedPerspectiveCameras:
         y = self.principal_point[cam_id, 1] - pc[..., 1] * self.focal_length[cam_id, 1] / pc[..., 2]
         return torch.stack([x, y], dim=-1), pc[..., 2]
 
+    def project_ndc(self, ps, cam_id=0):
+        """world points -> (x, y) in pytorch3d's NDC frame (+x left, +y up) and view-space depth: the reference's
+        get_projection_transform with screen-space intrinsics (model/CameraMine.py:44-70, _get_sfm_calibration_matrix
+        :171-262: fx_ndc = fx / (W/2), px_ndc = 1 - 1/W - cx / (W/2)) followed by the rasterisers' `z = z_view` override."""
+        W, H = float(self.image_size[cam_id, 0]), float(self.image_size[cam_id, 1])
+        pc = ps.matmul(self.R[cam_id]) + self.T[cam_id].view(1, 3)
+        f, c = self.focal_length[cam_id], self.principal_point[cam_id]
+        x = (f[0] / (W / 2.)) * pc[..., 0] / pc[..., 2] + (1. - 1. / W - c[0] / (W / 2.))
+        y = (f[1] / (H / 2.)) * pc[..., 1] / pc[..., 2] + (1. - 1. / H - c[1] / (H / 2.))
+        return torch.stack([x, y], dim=-1), pc[..., 2]
+
     def cam_pos(self, cam_id=0):
         return -self.R[cam_id].matmul(self.T[cam_id].view(-1, 1)).view(-1)
 

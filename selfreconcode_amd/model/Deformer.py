@@ -180,13 +180,24 @@ class LBSkinner(nn.Module):
                 G[i] = prod[:, n]
         return torch.stack(G, 1)
 
+    def _buffers_key(self):
+        # host copies of the buffers are keyed on (storage, version): load_state_dict / .to() / in-place edits refresh them
+        return tuple((t.data_ptr(), t._version) for t in (self.Js, self.init_pose, self.b_min, self.b_max))
+
     def _host_consts(self):
-        if not hasattr(self, "_hc"):
+        key = self._buffers_key()
+        if getattr(self, "_hc_key", None) != key:
             js = (ctypes.c_float * 72)(*self.Js.detach().cpu().view(-1).tolist())
             pa = (ctypes.c_int32 * 24)(*[max(p, 0) if i else 0 for i, p in enumerate(self.parents)])
             ip = (ctypes.c_float * 384)(*self.init_pose.detach().cpu().view(-1).tolist())
             self._hc = (js, pa, ip)
+            self._box = (self.b_min.view(-1).tolist(), self.b_max.view(-1).tolist())
+            self._hc_key = key
         return self._hc
+
+    def _box_consts(self):
+        self._host_consts()
+        return self._box
 
     def posed_chain(self, poses):
         """(G, A): posed kinematic chain and A = G @ init_pose, one fused launch each way (first-order autograd)."""
@@ -220,10 +231,9 @@ class LBSkinner(nn.Module):
         a.batch_inds = _lib.ptr(batch_inds)
         a.points_per_frame = 0 if batch_inds is not None else (ps.shape[1] if ps.dim() == 3 else P)
         a.vol, a.D, a.H, a.W = _lib.ptr(vol), vol.shape[1], vol.shape[2], vol.shape[3]
-        if not hasattr(self, "_box"):
-            self._box = (self.b_min.view(-1).tolist(), self.b_max.view(-1).tolist())
+        box = self._box_consts()
         for i in range(3):
-            a.bmin[i], a.bmax[i] = self._box[0][i], self._box[1][i]
+            a.bmin[i], a.bmax[i] = box[0][i], box[1][i]
         a.y, a.jac = _lib.ptr(y), _lib.ptr(jac)
         with torch.cuda.device(flat.device):
             _lib.call("sr_lbs_fwd", ctypes.byref(a), _lib.stream_of(flat))
@@ -274,8 +284,9 @@ class LBSkinner(nn.Module):
         a.A, a.trans, a.nframes = _lib.ptr(A12), 0, A.shape[0]
         a.batch_inds, a.points_per_frame = _lib.ptr(batch_inds), ppf
         a.vol, a.D, a.H, a.W = _lib.ptr(vol), vol.shape[1], vol.shape[2], vol.shape[3]
+        box = self._box_consts()
         for i in range(3):
-            a.bmin[i], a.bmax[i] = self._box[0][i], self._box[1][i]
+            a.bmin[i], a.bmax[i] = box[0][i], box[1][i]
         yb = ybar.contiguous().float()
         pbar = torch.empty_like(flat) if need_p else None
         Abar = torch.zeros((A.shape[0], 24, 12), device=flat.device) if need_A else None

@@ -8,9 +8,10 @@ Deliberate differences (all documented in DESIGN.md):
   * the deformation regulariser takes its singular values from the device SVD kernel instead of
     `torch.svd(Jacobs.cpu())` (network.py:576);
   * the two pytorch3d rasterisation calls (network.py:492,497 -- third-party code that is not in the
-    reference repository, parity unpinned) are replaced by stand-ins: a vertex z-buffer for the ray
-    seeds and an order-independent soft point splat for the silhouette.  Fragments from an external
-    mesh rasteriser can be passed in `datas['frags']` and then go through FindSurfacePs as in the reference;
+    reference repository; restated from pytorch3d 0.4.0 in oracle/raster_oracle.py, parity unpinned) are
+    served by in-repo HIP kernels with the same semantics (csrc/raster.hip: nearest-face rasteriser,
+    K=50 nearest-in-z point compositor).  Fragments from an external mesh rasteriser can be passed in
+    `datas['frags']` and then go through FindSurfacePs as in the reference;
   * random draws can be injected (`rand=`) so that parity tests feed both sides the same numbers.
 """
 import numpy as np
@@ -22,7 +23,7 @@ from .. import dist as srdist
 from .. import mlp_engine
 from ..ext import MCGpu
 from ..ext.FastMinv import Fast3x3Minv
-from ..ops import singular_values_3x3, splat_silhouette, rasterize_mesh
+from ..ops import singular_values_3x3, points_silhouette, rasterize_meshes
 from ..utils import utils as U
 from ..utils.FindSurfacePs import FindSurfacePs, OptimizeSurfacePs
 from .CameraMine import RectifiedPerspectiveCameras
@@ -143,8 +144,8 @@ class OptimNetwork(nn.Module):
             poses, trans, d_cond, rendcond = [t.detach() for t in self.dataset.get_grad_parameters(frame_ids, device)]
             defconds = [d_cond, [poses, trans]]
             defTmpVs = self.deformer(TmpVs[None, :, :].expand(N, -1, 3), defconds, ratio=ratio)
-            pix, z = cameras.project(defTmpVs)
-            frags = rasterize_mesh(pix, z, Tmpfs, H, W)
+            xy, z = cameras.project_ndc(defTmpVs)
+            frags = rasterize_meshes(xy, z, Tmpfs, H, W)
             batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(TmpVs, Tmpfs, frags)
             rays = cameras.view_rays(torch.stack([col_inds, row_inds, torch.ones_like(col_inds)], dim=-1).float())
             cam_pos = cameras.cam_pos().detach()
@@ -217,25 +218,46 @@ class OptimNetwork(nn.Module):
         return batch_inds, row_inds, col_inds, seeds
 
     def _silhouette(self, defTmpVs, cameras, H, W, radius):
-        pix, z = cameras.project(defTmpVs)
-        radius_px = radius * float(min(H, W)) / 2.0          # NDC radius -> pixels
-        return splat_silhouette(pix, z > 0, H, W, radius_px)
+        """pcRender of the reference (network.py:178-190, 497): PointsRasterizer(radius, points_per_pixel=50) + AlphaCompositor
+        over the deformed template vertices with one all-ones feature -> masks [N,H,W]."""
+        xy, z = cameras.project_ndc(defTmpVs)
+        return points_silhouette(xy, z, H, W, radius, 50)
 
     # ------------------------------------------------------------------ one training iteration
-    def forward(self, datas, sample_pix, ratio, frame_ids, root=None, rand=None, **kwargs):
+    def forward(self, datas, sample_pix, ratio, frame_ids, root=None, rand=None, debug=None, **kwargs):
+        """`rand` (extension): dict of pre-drawn random tensors (ray_select, vert_select, vert_select2, eik_local, eik_global,
+        regu_local; each may be longer than needed, the head is used) so that a parity test feeds both sides the same numbers;
+        `debug` (extension): a dict that receives the selected rays, their seeds and the refiner's output."""
         device = frame_ids.device
         rand = rand or {}
         gtCs = datas['img'].to(device)
         gtMs = datas['mask'].to(device)
         N = gtCs.shape[0]
         cameras, H, W = self._cameras(N, device)
+        # Learnable camera parameters (opt_camera, config.conf:12-17): the silhouette projection below is back-propagated INSIDE
+        # computeTmpPcLoss, which frees that camera graph (the quaternion -> R chain saves tensors); everything after it -- rays,
+        # camera centre, the normal branch -- needs a graph of its own.  The reference rebuilds its cameras after the inner backward
+        # for this reason (network.py:529-531 "rebuild the computation graph"); here the second object is built up front so that the
+        # side stream can use it.  Fixed cameras are one cached object.
+        cam_params = getattr(self.dataset, 'camera_params', None)
+        cam_learn = isinstance(cam_params, dict) and any(torch.is_tensor(v) and v.requires_grad for v in cam_params.values())
+        cameras_sil = cameras
+        if cam_learn:
+            cameras = self._cameras(N, device)[0]
         if self.angThred is None:
             self.angThred = cameras.angThreshold(0.5)
         self.info = {}
         if self.TmpVs is None or self.Tmpfs is None or self.forward_time % self.remesh_intersect == 0:
+            ev = getattr(self, 'remesh_events', None)
+            if ev is not None:                       # bench.py: duration of the remesh inside the timed window
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             self.TmpVs, self.Tmpfs = self.discretizeSDF(ratio, None, -self.sdfShrinkRadius)
+            if ev is not None:
+                e1.record(); ev.append((e0, e1))
             if self.TmpVs.shape[0] == 0:
                 raise AssertionError('tmp sdf vanished...')
+            srdist.assert_same_across_ranks(self.TmpVs.shape[0], "template vertex count after the remesh")
             self.remesh_time = 1. + np.floor(self.remesh_time)
             self.TmpVs.requires_grad = True
             self.TmpOptimizer = torch.optim.SGD([self.TmpVs], lr=0.05, momentum=0.9)
@@ -259,7 +281,7 @@ class OptimNetwork(nn.Module):
         fork.record(main)
         mlp_engine.PROFILE.overlap = True       # (bench.py's roofline leg: event pairs inside the two-stream window are not kernel durations)
 
-        masks = self._silhouette(defTmpVs, cameras, H, W, self.point_radius)
+        masks = self._silhouette(defTmpVs, cameras_sil, H, W, self.point_radius)
         radius = int(np.round(self.point_radius / 2. * float(min(H, W)) / 1.2))
         mgtMs = F.max_pool2d(gtMs, kernel_size=2 * radius + 1, stride=1, padding=radius) if radius > 0 else gtMs
         total_loss = self.computeTmpPcLoss(defTmpVs, defconds, masks, mgtMs, ratio)
@@ -270,8 +292,8 @@ class OptimNetwork(nn.Module):
                 if 'frags' in datas:
                     batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(seedVs, self.Tmpfs, datas['frags'])
                 elif self.seed_mode == "mesh":            # in-repo hard mesh rasteriser -> FindSurfacePs, as the reference does with pytorch3d
-                    pix, z = cameras.project(defTmpVs.detach())
-                    frags = rasterize_mesh(pix, z, self.Tmpfs, H, W)
+                    xy, z = cameras.project_ndc(defTmpVs.detach())
+                    frags = rasterize_meshes(xy, z, self.Tmpfs, H, W)
                     batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(seedVs, self.Tmpfs, frags)
                 else:
                     batch_inds, row_inds, col_inds, initTmpPs = self._seed_rays(defTmpVs.detach(), cameras, H, W, seedVs)
@@ -281,7 +303,7 @@ class OptimNetwork(nn.Module):
             pnum = batch_inds.shape[0]
             sample_pix = self.conf.get_int('sample_pix_num') if 'sample_pix_num' in self.conf else sample_pix
             if pnum > sample_pix * N:
-                u = rand['ray_select'] if 'ray_select' in rand else torch.rand(pnum, device=device)
+                u = rand['ray_select'][:pnum] if 'ray_select' in rand else torch.rand(pnum, device=device)
                 sel = (u < float(sample_pix * N) / float(pnum)).nonzero(as_tuple=False).view(-1)
                 batch_inds, row_inds, col_inds, initTmpPs = batch_inds[sel], row_inds[sel], col_inds[sel], initTmpPs[sel]
                 pnum = batch_inds.shape[0]
@@ -290,20 +312,28 @@ class OptimNetwork(nn.Module):
             initTmpPs = initTmpPs.contiguous()
             # vertex subsets of the eikonal / def-regu samples: the Bernoulli masks do not depend on the vertex positions, so their
             # index lists (one host sync each) are made here; the gathers happen after the template step, as in the reference
-            vsel = rand['vert_select'] if 'vert_select' in rand else torch.rand(TmpVnum, device=device)
+            vsel = rand['vert_select'][:TmpVnum] if 'vert_select' in rand else torch.rand(TmpVnum, device=device)
             eik_idx = (vsel < 4096. / float(TmpVnum)).nonzero(as_tuple=False).view(-1)
             use_regu = 'def_regu' in self.conf and self.conf.get_float('def_regu.weight') > 0.
             regu_idx = None
             if use_regu:
-                vsel2 = rand['vert_select2'] if 'vert_select2' in rand else torch.rand(TmpVnum, device=device)
+                vsel2 = rand['vert_select2'][:TmpVnum] if 'vert_select2' in rand else torch.rand(TmpVnum, device=device)
                 regu_idx = (vsel2 < 4096. / float(TmpVnum)).nonzero(as_tuple=False).view(-1)
             # the refiner (no autograd, thousands of small launches with 3 tiles per CU) stays on the side stream: it runs
             # CONCURRENTLY with the template branch, whose large kernels fill the gaps and tails it leaves
+            if debug is not None:
+                debug.update(batch_inds=batch_inds, row_inds=row_inds, col_inds=col_inds, seeds=initTmpPs.clone())
             with torch.no_grad():
                 poses_s, trans_s, d_cond_s, _ = self.dataset.get_grad_parameters(frame_ids, device)
+                rev = getattr(self, 'refiner_events', None)
+                if rev is not None:                  # bench.py: time the refiner occupies on its stream (it shares the GPU with the template branch)
+                    r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    r0.record(side)
                 initTmpPs, check = OptimizeSurfacePs(cameras.cam_pos().detach(), rays.detach(), initTmpPs, batch_inds, self.sdf, ratio,
                                                      self.deformer, [d_cond_s, [poses_s, trans_s]], dthreshold=5.e-5,
                                                      athreshold=self.angThred, w1=3.05, w2=1., times=10)
+                if rev is not None:
+                    r1.record(side); rev.append((r0, r1))
             refined = torch.cuda.Event()
             refined.record(side)
         main.wait_stream(side)
@@ -316,18 +346,39 @@ class OptimNetwork(nn.Module):
         defconds = [d_cond, [poses, trans]]
         self.info['rayInfo'] = (check.numel(), check.sum())
         self.TmpPs = None
+        if debug is not None:
+            debug.update(initTmpPs=initTmpPs, check=check, rays=rays)
 
         # --- eikonal (network.py:543-549)
         base = torch.cat([initTmpPs, self.TmpVs.detach()[eik_idx]], dim=0)
         grad_loss = self.loss_eikonal(base, ratio, rand.get('eik_local'), rand.get('eik_global'))
         self.info['grad_loss'] = grad_loss.detach()
+        wpool = srdist.pooled_mean_weight(base.shape[0], device)      # N > 1 ranks: pooled mean over the points of all ranks (caveat B)
+        if wpool is not None:
+            grad_loss = grad_loss * wpool
         total_loss = total_loss + grad_loss * self.conf.get_float('grad_weight')
+
+        # --- offset regulariser (network.py:552-560): mean |deformation-MLP offset| on the eikonal sample points; logged without
+        # gradient when its weight is 0 (both shipped configs), part of the loss when it is positive
+        ow = self.conf.get_float('offset_weight') if 'offset_weight' in self.conf else -1.
+        if ow > 0.:
+            self.deformer.defs[0](self._eik_pts.view(1, -1, 3).expand(N, -1, 3), d_cond, ratio=ratio)
+            offset_loss = self.deformer.defs[0].offset.view(-1, 3).norm(p=2, dim=-1).mean()
+            total_loss = total_loss + offset_loss * ow
+            self.info['offset_loss'] = offset_loss.detach()
+        elif ow == 0.:
+            with torch.no_grad():
+                self.deformer.defs[0](self._eik_pts.view(1, -1, 3).expand(N, -1, 3), d_cond.detach(), ratio=ratio)
+                self.info['offset_loss'] = self.deformer.defs[0].offset.view(-1, 3).norm(p=2, dim=-1).mean()
 
         # --- deformation regulariser (network.py:565-582)
         if use_regu:
             pts = torch.cat([initTmpPs, self.TmpVs.detach()[regu_idx]], dim=0)
             def_loss = self.loss_def_regu(pts, d_cond, N, ratio, rand.get('regu_local'))
             self.info['def_loss'] = def_loss.detach()
+            wpool = srdist.pooled_mean_weight(pts.shape[0], device)
+            if wpool is not None:
+                def_loss = def_loss * wpool
             total_loss = total_loss + def_loss * self.conf.get_float('def_regu.weight')
 
         # --- DCT temporal smoothness (network.py:585-593)
@@ -362,20 +413,18 @@ class OptimNetwork(nn.Module):
     # ------------------------------------------------------------------ loss terms (a14)
     def loss_eikonal(self, base, ratio, noise_local=None, noise_global=None):
         """sample_points (utils.py:74-84) + ((|grad f| - 1)^2).mean()."""
-        if noise_local is None:
-            noise_local = torch.randn_like(base)
         n_global = base.shape[0] // 6
-        if noise_global is None:
-            noise_global = torch.rand(n_global, 3, device=base.device)
+        noise_local = torch.randn_like(base) if noise_local is None else noise_local[:base.shape[0]]
+        noise_global = torch.rand(n_global, 3, device=base.device) if noise_global is None else noise_global[:n_global]
         pts = torch.cat([base + noise_local * 0.01, noise_global * (1.8 * 2) - 1.8], dim=0)
+        self._eik_pts = pts.detach()
         pts.requires_grad_()
         pred = self.sdf(pts, ratio, sdf_only=True)
         grad = self.sdf.gradient(pts, pred)
         return ((grad.norm(2, dim=-1) - 1) ** 2).mean()
 
     def loss_def_regu(self, pts, d_cond, N, ratio, noise_local=None):
-        if noise_local is None:
-            noise_local = torch.randn_like(pts)
+        noise_local = torch.randn_like(pts) if noise_local is None else noise_local[:pts.shape[0]]
         pts = torch.cat([pts, pts + noise_local * 0.01], dim=0).view(1, -1, 3).expand(N, -1, 3)
         from .Deformer import translator_value_jacobian
         _, Jacobs = translator_value_jacobian(self.deformer.defs[0], pts.contiguous(), d_cond, None, ratio)   # forward-mode Jacobian
@@ -453,7 +502,10 @@ class OptimNetwork(nn.Module):
             loss = loss + consistent_loss * cw
         self.TmpOptimizer.zero_grad()
         loss.backward()                              # (deferred weight gradients stay in their buffers until propagateTmpPsGrad flushes)
-        srdist.all_reduce_mean_(self.TmpVs.grad)     # shared template: exact batch semantics across ranks
+        if srdist.is_distributed():                  # shared template: exact batch semantics across ranks (every rank joins, zeros if no gradient)
+            if self.TmpVs.grad is None:
+                self.TmpVs.grad = torch.zeros_like(self.TmpVs)
+            srdist.all_reduce_mean_(self.TmpVs.grad)
         self.TmpOptimizer.step()
         mnfld_pred = self.sdf(self.TmpVs, ratio, sdf_only=True).view(-1)
         sdf_loss = (mnfld_pred + self.sdfShrinkRadius).abs().mean()
@@ -461,9 +513,14 @@ class OptimNetwork(nn.Module):
         return sdf_loss * (self.conf.get_float('pc_weight.weight') if 'pc_weight' in self.conf else 60.)
 
     # ------------------------------------------------------------------ implicit differentiation (a15)
-    def propagateTmpPsGrad(self, frame_ids, ratio):
+    def propagateTmpPsGrad(self, frame_ids, ratio, overlap=None):
         """After loss.backward(): push d loss / d TmpPs into the SDF, deformer, per-frame codes / poses / trans
-        through the constraint system f(p) = 0, [v]x (d(p) - c) = 0 (network.py:702-814)."""
+        through the constraint system f(p) = 0, [v]x (d(p) - c) = 0 (network.py:702-814).
+        `overlap` (extension): a dist.GradBucket whose early group (gradients this pass does not touch) is all-reduced
+        asynchronously while the pass runs."""
+        if overlap is not None and srdist.is_distributed():
+            mlp_engine.flush_param_grads(only=overlap.early_ids)      # their deferred weight gradients are final: materialise them now
+            overlap.start_early()
         if self.TmpPs is None or self.TmpPs.grad is None:
             self.info['invInfo'] = (-1, -1)
             mlp_engine.flush_param_grads()

@@ -30,35 +30,42 @@ def singular_values_3x3(J):
     return SingularValues3x3.apply(J)
 
 
-class SplatSilhouette(Function):
-    """mask[N,H,W] = 1 - prod_k (1 - a_k) over the points splatted within `radius_px` of each pixel."""
+class PointsSilhouette(Function):
+    """mask[N,H,W] of pytorch3d's PointsRasterizer(radius, points_per_pixel=K) + AlphaCompositor with one all-ones feature, as
+    the reference renders the deformed template vertices (model/network.py:495-497, model/CameraMine.py:285-305): per pixel
+    the K covering points nearest in z, composited front to back with a = 1 - dist2 / radius^2 (NDC units)."""
 
     @staticmethod
-    def forward(ctx, pix, vis, H, W, radius_px):
-        _lib.require_gpu(pix)
-        pix = pix.contiguous().float()
-        N, V = pix.shape[0], pix.shape[1]
-        visb = None if vis is None else vis.contiguous().to(torch.uint8)
-        logT = torch.zeros((N, H, W), dtype=torch.float32, device=pix.device)
-        with torch.cuda.device(pix.device):
-            _lib.call("sr_splat_fwd", _lib.ptr(pix), _lib.ptr(visb), N, V, H, W, float(radius_px), _lib.ptr(logT), _lib.stream_of(pix))
-        ctx.save_for_backward(pix, visb, logT)
-        ctx.dims = (H, W, float(radius_px))
-        return 1.0 - torch.exp(logT)
+    def forward(ctx, xy_ndc, z, H, W, radius, K):
+        _lib.require_gpu(xy_ndc)
+        xy = xy_ndc.detach().contiguous().float(); zz = z.detach().contiguous().float()
+        N, V = xy.shape[0], xy.shape[1]
+        nbytes = _lib.raw("sr_points_silhouette_workspace_bytes")(N, V, H, W, float(radius))
+        if nbytes < 0:
+            raise _lib.SrError("sr_points_silhouette_workspace_bytes: bad argument")
+        ws = torch.empty((max(int(nbytes), 256) + 255,), dtype=torch.uint8, device=xy.device)
+        off = (-ws.data_ptr()) % 256
+        mask = torch.empty((N, H, W), dtype=torch.float32, device=xy.device)
+        with torch.cuda.device(xy.device):
+            _lib.call("sr_points_silhouette_fwd", _lib.ptr(xy), _lib.ptr(zz), N, V, H, W, float(radius), int(K), _lib.ptr(mask),
+                      ws.data_ptr() + off, _lib.stream_of(xy))
+        ctx.save_for_backward(xy, zz, ws)
+        ctx.dims = (H, W, float(radius), off)
+        return mask
 
     @staticmethod
     def backward(ctx, gmask):
-        pix, visb, logT = ctx.saved_tensors
-        H, W, r = ctx.dims
-        gpix = torch.empty_like(pix)
-        with torch.cuda.device(pix.device):
-            _lib.call("sr_splat_bwd", _lib.ptr(pix), _lib.ptr(visb), pix.shape[0], pix.shape[1], H, W, r, _lib.ptr(logT),
-                      _lib.ptr(gmask.contiguous().float()), _lib.ptr(gpix), _lib.stream_of(pix))
-        return gpix, None, None, None, None
+        xy, zz, ws = ctx.saved_tensors
+        H, W, radius, off = ctx.dims
+        gxy = torch.empty_like(xy)
+        with torch.cuda.device(xy.device):
+            _lib.call("sr_points_silhouette_bwd", _lib.ptr(xy), _lib.ptr(zz), xy.shape[0], xy.shape[1], H, W, radius, ws.data_ptr() + off,
+                      _lib.ptr(gmask.contiguous().float()), _lib.ptr(gxy), _lib.stream_of(xy))
+        return gxy, None, None, None, None, None
 
 
-def splat_silhouette(pix, vis, H, W, radius_px):
-    return SplatSilhouette.apply(pix, vis, H, W, radius_px)
+def points_silhouette(xy_ndc, z, H, W, radius, points_per_pixel=50):
+    return PointsSilhouette.apply(xy_ndc, z, H, W, radius, points_per_pixel)
 
 
 class Fragments:
@@ -68,17 +75,18 @@ class Fragments:
         self.pix_to_face, self.bary_coords, self.zbuf = pix_to_face, bary_coords, zbuf
 
 
-def rasterize_mesh(pix, z, faces, H, W):
-    """No-grad hard rasterisation of N images of one mesh topology (see sr_raster_mesh)."""
-    _lib.require_gpu(pix)
-    pix = pix.detach().contiguous().float(); z = z.detach().contiguous().float(); faces = faces.contiguous()
-    N, V = pix.shape[0], pix.shape[1]
-    dev = pix.device
+def rasterize_meshes(xy_ndc, z, faces, H, W):
+    """No-grad hard rasterisation of N images of one mesh topology with the semantics of the reference's MeshRasterizer
+    settings (model/network.py:877-892; see sr_rasterize_meshes)."""
+    _lib.require_gpu(xy_ndc)
+    xy = xy_ndc.detach().contiguous().float(); z = z.detach().contiguous().float(); faces = faces.contiguous()
+    N, V = xy.shape[0], xy.shape[1]
+    dev = xy.device
     zbuf = torch.empty((N, H, W), dtype=torch.int64, device=dev)
     p2f = torch.empty((N, H, W), dtype=torch.int64, device=dev)
     bary = torch.empty((N, H, W, 3), dtype=torch.float32, device=dev)
     zo = torch.empty((N, H, W), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.call("sr_raster_mesh", _lib.ptr(pix), _lib.ptr(z), _lib.ptr(faces), N, V, faces.shape[0], H, W, _lib.ptr(zbuf), _lib.ptr(p2f),
-                  _lib.ptr(bary), _lib.ptr(zo), _lib.stream_of(pix))
+        _lib.call("sr_rasterize_meshes", _lib.ptr(xy), _lib.ptr(z), _lib.ptr(faces), N, V, faces.shape[0], H, W, _lib.ptr(zbuf), _lib.ptr(p2f),
+                  _lib.ptr(bary), _lib.ptr(zo), _lib.stream_of(xy))
     return Fragments(p2f.unsqueeze(-1), bary.unsqueeze(3), zo.unsqueeze(-1))

@@ -2,11 +2,15 @@
 
 FindSurfacePs   (:5-29)   rasteriser fragments -> canonical seed points.
 OptimizeSurfacePs (:114-163) the masked Newton refiner ("the tracer").  When given this package's
-ImplicitNetwork + CompositeDeformer([MLPTranslator, LBSkinner]) it runs the fused path: per
-iteration ONE group-4 (value + 3 forward tangents) evaluation of the sdf-only SDF MLP and of the
-deformation MLP, the fused LBS+Jacobian kernel and one Newton-update kernel -- no autograd graph,
-no per-frame Python loop.  The convergence test of iteration k and the gradient of iteration k+1
-are taken from the same evaluation (the reference evaluates the same points twice).
+ImplicitNetwork + CompositeDeformer([MLPTranslator, LBSkinner]) it runs the device-driven path
+(`_optimize_device_driven`): the queue of unfinished rays is compacted on the GPU after every step and
+every row count stays in device memory; per Newton step the host issues five launches -- first-layer
+inputs of both networks, ONE persistent chain over all forward layers of the sdf-only SDF MLP and the
+deformation MLP side by side, LBS + Jacobian + convergence test + residual cotangents, one persistent
+chain over all reverse layers, Newton update + retirement + compaction -- with no autograd graph, no
+per-frame Python loop and no host synchronisation.  The convergence test of step k and the gradient
+of step k+1 come from the same evaluation (the reference evaluates the same points twice).
+`DEVICE_DRIVEN = False` keeps the earlier layer-by-layer host loop (same arithmetic per ray).
 """
 import ctypes
 import numpy as np
@@ -148,6 +152,161 @@ def _newton(ev, x, bi, rays, cam, group, dthr, athr, w1, w2, update):
     return xnew, conv
 
 
+# ------------------------------------------------------------------------------------------------
+# Device-driven refiner: the queue of unfinished rays, its compaction and every row count stay on the GPU
+# (csrc/refiner.hip + the persistent layer chains of csrc/mlp_gemm.hip); the host issues a FIXED sequence of
+# 3 + 5*times + 3 launches per call and never synchronises.
+DEVICE_DRIVEN = True
+_WORKSPACES = {}     # (device, capacity) -> _RefinerWorkspace
+_ERROR_WATCH = {}    # device -> (pinned int32, event) of the previous call's barrier-failure flag
+
+
+class _RefinerWorkspace:
+    def __init__(self, dev, cap, ev, times_cap):
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        i = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+        self.cap, self.times_cap = cap, times_cap
+        self.live = torch.zeros(times_cap + 3, dtype=torch.int32, device=dev)
+        self.sync = torch.zeros(4, dtype=torch.int32, device=dev)            # [0] chain barrier counter, [1] barrier-failure flag
+        self.x, self.v = [f(cap, 3), f(cap, 3)], [f(cap, 3), f(cap, 3)]
+        self.frame, self.orig = [i(cap), i(cap)], [i(cap), i(cap)]
+        self.unit, self.t, self.s = f(cap, 4), f(cap, 4), f(cap)
+        self.conv = torch.empty(cap, dtype=torch.uint8, device=dev)
+        sl, dl = ev.sdf_spec.layers, ev.tr.spec.layers
+        self.a0, self.a0d = f(cap, me.pad4(ev.sdf_spec.K0)), f(cap, me.pad4(ev.tr.spec.K0))
+        self.sdf_act = [f(cap, me.pad4(L.N + L.nfill)) for L in sl]
+        self.def_act = [f(cap, me.pad4(L.N + L.nfill)) for L in dl]
+        self.sdf_zbar = [None] + [f(cap, me.pad4(L.K)) for L in sl[1:]]       # cotangent of layer l's INPUT (own buffer per layer:
+        self.def_zbar = [None] + [f(cap, me.pad4(L.K)) for L in dl[1:]]       # the skip part of one of them is read at the end)
+        self.a0bar, self.a0dbar = f(cap, me.pad4(ev.sdf_spec.K0)), f(cap, me.pad4(ev.tr.spec.K0))
+        self.pinned_err = torch.zeros(1, dtype=torch.int32).pin_memory()
+
+
+def _fill_gemm(g, A, B, C, N, K, bias, act, mode, out_scale=1.0, aux=None, naux_fwd=0, nact_bwd=0, aux_scale=1.0):
+    g.A, g.lda, g.B, g.ldb, g.C, g.ldc = _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(C), C.stride(0)
+    g.M, g.N, g.K, g.bias = 0, N, K, _lib.ptr(bias)
+    g.group, g.act, g.mode, g.out_scale = 1, act, mode, out_scale
+    g.aux, g.ldaux, g.naux_fwd, g.nact_bwd, g.aux_scale = _lib.ptr(aux), 0 if aux is None else aux.stride(0), naux_fwd, nact_bwd, aux_scale
+
+
+def _forward_chain(ws, ev):
+    c = _lib.SrChainArgs()
+    nets = ((ev.sdf_spec, ev.sdf_W, ev.sdf_b, ws.a0, ws.sdf_act), (ev.tr.spec, ev.def_W, ev.def_b, ws.a0d, ws.def_act))
+    c.nlayers = max(len(n[0].layers) for n in nets)
+    for l in range(c.nlayers):
+        k = 0
+        for spec, W, b, a0, acts in nets:
+            if l >= len(spec.layers):
+                continue
+            L = spec.layers[l]
+            _fill_gemm(c.g[l][k], a0 if l == 0 else acts[l - 1], W[l], acts[l], L.N, L.K, b[l], L.act, me.EPI_FWD, out_scale=L.out_scale,
+                       aux=a0 if L.nfill else None, naux_fwd=L.nfill)
+            k += 1
+        c.nprob[l] = k
+    return c
+
+
+def _reverse_chain(ws, ev):
+    """me.reverse (input gradient only) of both networks, layer by layer from the outputs: SDF cotangent rows (1,0,0,0), deformer
+    cotangent rows `t`."""
+    c = _lib.SrChainArgs()
+    nets = ((ev.sdf_spec, ev.sdf_WT, ws.a0, ws.sdf_act, ws.sdf_zbar, ws.unit, ws.a0bar), (ev.tr.spec, ev.def_WT, ws.a0d, ws.def_act, ws.def_zbar, ws.t, ws.a0dbar))
+    c.nlayers = max(len(n[0].layers) for n in nets)
+    for r in range(c.nlayers):
+        k = 0
+        for spec, WT, a0, acts, zbar, ybar, a0bar in nets:
+            nl = len(spec.layers)
+            l = nl - 1 - r
+            if l < 0:
+                continue
+            L = spec.layers[l]
+            src = ybar if l == nl - 1 else zbar[l + 1]
+            if l > 0:
+                Pv = spec.layers[l - 1]
+                _fill_gemm(c.g[r][k], src, WT[l], zbar[l], L.K, L.N, None, Pv.act, me.EPI_BWD, out_scale=Pv.out_scale, aux=acts[l - 1], nact_bwd=Pv.N,
+                           aux_scale=Pv.out_scale)
+            else:
+                _fill_gemm(c.g[r][k], src, WT[0], a0bar, L.K, L.N, None, me.ACT_NONE, me.EPI_FWD)
+            k += 1
+        c.nprob[r] = k
+    return c
+
+
+def _optimize_device_driven(ev, cam, rays, initTmpPs, batch_inds, dthreshold, athreshold, w1, w2, times):
+    dev = initTmpPs.device
+    P = initTmpPs.shape[0]
+    watch = _ERROR_WATCH.pop(dev, None)
+    if watch is not None:
+        watch[1].synchronize()
+        if int(watch[0][0]) != 0:
+            raise _lib.SrError("sr_mlp_chain: the device-wide barrier of the previous refiner call gave up (persistent grid not resident)")
+    cap = (P + 1023) // 1024 * 1024
+    key = (dev, cap)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.times_cap < times:
+        for k in [k for k in _WORKSPACES if k[0] == dev and k[1] != cap and len(_WORKSPACES) > 3]:
+            del _WORKSPACES[k]
+        ws = _WORKSPACES[key] = _RefinerWorkspace(dev, cap, ev, max(times, 30))
+    x0 = initTmpPs.contiguous().float()
+    bi = batch_inds.contiguous()
+    p_out = torch.empty_like(x0)
+    conv_out = torch.empty(P, dtype=torch.uint8, device=dev)
+    a = _lib.SrRefineArgs()
+    a.P, a.times = P, times
+    a.p0, a.rays, a.batch_inds, a.cam = _lib.ptr(x0), _lib.ptr(rays), _lib.ptr(bi), _lib.ptr(cam)
+    a.L_sdf, a.w_sdf, a.L_def, a.w_def = ev.sdf.multires, _lib.ptr(ev.w_sdf), ev.tr.multires, _lib.ptr(ev.w_def)
+    a.conds, a.ld_conds, a.E = _lib.ptr(ev.conds), ev.conds.stride(0), ev.conds.shape[1]
+    A12 = ev.A[:, :, :3, :].contiguous()
+    vol = ev.skin.ws.permute(0, 2, 3, 4, 1)
+    a.A, a.trans, a.nframes = _lib.ptr(A12), _lib.ptr(ev.trans), A12.shape[0]
+    a.vol, a.D, a.H, a.W = _lib.ptr(vol), vol.shape[1], vol.shape[2], vol.shape[3]
+    box = ev.skin._box_consts()
+    for i in range(3):
+        a.bmin[i], a.bmax[i] = box[0][i], box[1][i]
+    a.dthreshold, a.athreshold, a.w1, a.w2 = dthreshold, athreshold, w1, w2
+    a.live = _lib.ptr(ws.live)
+    for i in range(2):
+        a.x[i], a.v[i], a.frame[i], a.orig[i] = _lib.ptr(ws.x[i]), _lib.ptr(ws.v[i]), _lib.ptr(ws.frame[i]), _lib.ptr(ws.orig[i])
+    a.unit, a.conv, a.t, a.s = _lib.ptr(ws.unit), _lib.ptr(ws.conv), _lib.ptr(ws.t), _lib.ptr(ws.s)
+    a.a0, a.ld_a0, a.a0d, a.ld_a0d = _lib.ptr(ws.a0), ws.a0.stride(0), _lib.ptr(ws.a0d), ws.a0d.stride(0)
+    a.sdf_out, a.ld_sdf, a.def_out, a.ld_def = _lib.ptr(ws.sdf_act[-1]), ws.sdf_act[-1].stride(0), _lib.ptr(ws.def_act[-1]), ws.def_act[-1].stride(0)
+    a.a0bar, a.ld_a0bar, a.a0dbar, a.ld_a0dbar = _lib.ptr(ws.a0bar), ws.a0bar.stride(0), _lib.ptr(ws.a0dbar), ws.a0dbar.stride(0)
+    a.skipbar, a.ld_skipbar, a.n_skip = 0, 0, 0
+    for l, L in enumerate(ev.sdf_spec.layers):                      # the skip concat: cotangent of the filler columns of layer l's output
+        if L.nfill:
+            z = ws.sdf_zbar[l + 1]
+            a.skipbar, a.ld_skipbar, a.n_skip = z.data_ptr() + 4 * L.N, z.stride(0), L.nfill
+    a.p_out, a.conv_out = _lib.ptr(p_out), _lib.ptr(conv_out)
+    fwd, rev = _forward_chain(ws, ev), _reverse_chain(ws, ev)
+    for c in (fwd, rev):
+        c.m_mul, c.barrier, c.error = 1, ws.sync.data_ptr(), ws.sync.data_ptr() + 4
+    with torch.cuda.device(dev):
+        st = _lib.stream_of(x0)
+        ra = ctypes.byref(a)
+        _lib.call("sr_refine_init", ra, st)
+
+        def evaluate(phase):
+            _lib.call("sr_refine_embed", ra, phase, st)
+            fwd.m_dev = ws.live.data_ptr() + 4 * phase
+            _lib.call("sr_mlp_chain", ctypes.byref(fwd), st)
+        evaluate(0)
+        _lib.call("sr_refine_mid", ra, 0, 0, st)
+        for k in range(1, times + 1):
+            evaluate(k)
+            _lib.call("sr_refine_mid", ra, k, 1, st)
+            rev.m_dev = ws.live.data_ptr() + 4 * k
+            _lib.call("sr_mlp_chain", ctypes.byref(rev), st)
+            _lib.call("sr_refine_finish", ra, k, st)
+        evaluate(times + 1)
+        _lib.call("sr_refine_mid", ra, times + 1, 2, st)
+        ws.pinned_err.copy_(ws.sync[1:2], non_blocking=True)
+        e = torch.cuda.Event(); e.record()
+        _ERROR_WATCH[dev] = (ws.pinned_err, e)
+    x0.record_stream(torch.cuda.current_stream(dev)); bi.record_stream(torch.cuda.current_stream(dev))
+    initTmpPs.copy_(p_out)
+    return initTmpPs.detach(), conv_out.bool(), ws
+
+
 _PINNED = {}   # device -> pinned int64 scratch for the asynchronous live-ray counts
 COMPACT_BELOW = 0.5   # compact the working set once fewer than this fraction of its rays are still unfinished
 
@@ -171,6 +330,9 @@ def OptimizeSurfacePs(cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio, defor
         finished = torch.zeros(P, dtype=torch.bool, device=dev)
         if P == 0:
             return initTmpPs.detach(), finished
+        if DEVICE_DRIVEN:
+            ps, ok, _ = _optimize_device_driven(ev, cam, rays, initTmpPs, batch_inds, dthreshold, athreshold, w1, w2, times)
+            return ps, ok
         pin = _PINNED.get(dev)
         if pin is None or pin.numel() < times + 2:
             pin = _PINNED[dev] = torch.zeros(times + 2, dtype=torch.int64).pin_memory()

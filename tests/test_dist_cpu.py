@@ -29,10 +29,32 @@ def _worker(rank, world, port, out):
     loss = sum((net(data[f]) ** 2).mean() + (per_frame[f] - f).pow(2).sum() * 0.1 for f in mine) / len(mine)
     loss.backward()
     params = list(net.parameters()) + [unused, per_frame]
-    bucket = srdist.GradBucket(params)
+    # two buffers: `per_frame` stands for the gradients that are final early (render network) and is reduced asynchronously
+    bucket = srdist.GradBucket(params, early=[per_frame])
+    bucket.start_early()
     bucket.all_reduce_mean()
     tv = torch.full((5, 3), float(rank + 1))
     srdist.all_reduce_mean_(tv)
+    # replicas are made identical by a broadcast, not by trusting the seeds
+    drift = torch.nn.Parameter(torch.full((4,), float(rank)))
+    srdist.GradBucket([drift]).sync_initial_state()
+    assert drift.detach().tolist() == [0.0] * 4
+    # pooled-mean weights (caveat B): ranks holding 1 and 2 points -> 2/3 and 4/3
+    w = srdist.pooled_mean_weight(rank + 1, torch.device("cpu"))
+    assert abs(float(w) - (rank + 1) * 2.0 / 3.0) < 1e-6
+    srdist.assert_same_across_ranks(17, "vertex count")
+    try:
+        srdist.assert_same_across_ranks(17 + rank, "vertex count")
+        raised = False
+    except RuntimeError:
+        raised = True
+    assert raised
+    try:
+        srdist.all_reduce_mean_(None)
+        raised = False
+    except RuntimeError:
+        raised = True
+    assert raised
     # by value (numpy): a tensor on a multiprocessing queue travels as a shared-memory handle that dies with this process
     out.put((rank, [p.grad.numpy().copy() for p in params], tv.numpy().copy()))
     dist.destroy_process_group()

@@ -6,7 +6,7 @@ What the comparison says (asserted below):
   * face topology (after ordering vertices by lattice-edge key and sorting face rows) is identical in both builds of the
     reference (with / without mul+add contraction) and equal to the restatement and to the HIP kernels;
   * vertex coordinates are bit-equal to the CONTRACTED build (nvcc's default -fmad=true; the only contraction that
-    changes a bit is the v*step+min of d_scale_vertices) and one rounding of the product v*step (< 2^-22 here) away from the uncontracted one.
+    changes a bit is the v*step+min of d_scale_vertices) and one rounding of the product v*step (< 2^-20 here) away from the uncontracted one.
 The committed fixture tests/golden/mc_ref.npz (made by oracle/gen_mc_ref_golden.py from the contracted build) keeps the
 pin in force where neither /root/reference nor the prebuilt oracle/_ref files exist."""
 import os
@@ -46,7 +46,7 @@ def test_restatement_equals_reference_kernels(shape, kind):
     assert np.array_equal(kf, kn) and np.array_equal(ff, fn)          # topology does not depend on the contraction mode
     assert np.array_equal(ko, kf) and np.array_equal(fo, ff)          # restatement == reference: vertex set and faces
     assert np.array_equal(vo, vf)                                     # coordinates: bit-equal to the contracted (nvcc default) build
-    assert np.abs(vo - vn).max() <= 2.0 ** -22                        # uncontracted build: one rounding of the product (|v*step| < 4) apart
+    assert np.abs(vo - vn).max() <= 2.0 ** -20                        # uncontracted build: one rounding of the product (|v*step| < 16) apart
     if kind == "open":
         assert (fo < 0).any()
     else:

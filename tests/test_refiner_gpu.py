@@ -1,0 +1,113 @@
+"""The device-driven refiner (csrc/refiner.hip + the persistent layer chains): (1) a chain launch equals the layer-by-layer
+launches bit for bit, on a row count read from device memory; (2) the compacting refiner returns the same points / flags as the
+layer-by-layer host loop on a batch where rays finish at every step, leave no ray behind, and is deterministic;
+(3) launch count per call = 3 + 5*times + 3 (+1 init)."""
+import ctypes
+import numpy as np
+import pytest
+import torch
+from oracle import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RATIO = {'sdfRatio': 1.0, 'deformerRatio': 0.62, 'renderRatio': 1.0}
+
+
+def _nets():
+    from selfreconcode_amd.model.network import getTmpSdf
+    from selfreconcode_amd.model.Deformer import MLPTranslator, LBSkinner, CompositeDeformer
+    from selfreconcode_amd.utils.utils import smpl_tmp_Apose
+    sdf = getTmpSdf(DEV, 6, 0.6, 256); sdf.load_state_dict(fx.sphere_sdf_params(7), strict=True)
+    tr = MLPTranslator(128, 6).to(DEV); tr.load_state_dict(fx.det_params(fx.DEF_SPEC, 202, last_scale=0.05), strict=True)
+    skin = LBSkinner(fx.synthetic_lbs_volume((9, 29, 17)), fx.LBS_BMIN, fx.LBS_BMAX, fx.synthetic_joints(), np.array(fx.SMPL_PARENTS),
+                     init_pose=torch.from_numpy(smpl_tmp_Apose(1)), align_corners=False).to(DEV)
+    return sdf, CompositeDeformer([tr, skin]).to(DEV)
+
+
+def _rays(P, N=3, jitter=2e-3):
+    """Seeds near the sphere-like zero set along camera rays: most need 1-6 Newton steps, some start converged."""
+    cam = torch.tensor([0., 0.15, 2.4])
+    d = torch.nn.functional.normalize(fx.det_tensor((P, 3), 5, 1.0) * torch.tensor([0.22, 0.22, 0.05]) + torch.tensor([0., -0.05, -1.0]), dim=1)
+    # intersection of the ray with the sphere |x| = 0.6 (the SDF is a near-sphere), then a small push off the surface
+    b = (cam * d).sum(1); c = (cam * cam).sum() - 0.36
+    t = -b - torch.sqrt((b * b - c).clamp(min=0))
+    p = cam + t[:, None] * d
+    p = p + fx.det_tensor((P, 3), 6, 1.0) * jitter * (torch.arange(P) % 4 != 0).float()[:, None]
+    return cam, d, p, torch.arange(P) % N
+
+
+def test_chain_equals_layerwise_launches_on_a_device_row_count():
+    from selfreconcode_amd import _lib, mlp_engine as me
+    from selfreconcode_amd.utils import FindSurfacePs as F
+    sdf, comp = _nets()
+    N = 3
+    defconds = [fx.det_tensor((N, 128), 3, 0.1).to(DEV), [fx.det_tensor((N, 24, 3), 1, 0.1).to(DEV), fx.det_tensor((N, 3), 2, 0.05).to(DEV)]]
+    with torch.no_grad():
+        ev = F._FusedEval(sdf, comp, defconds, RATIO)
+        P, M = 3000, 1777                                    # capacity 3072 rows, 1777 of them live
+        ws = F._RefinerWorkspace(torch.device(DEV), 3072, ev, 10)
+        x = (fx.det_tensor((P, 3), 9, 0.6)).to(DEV)
+        bi = (torch.arange(P) % N).to(DEV)
+        A0 = ev._embed(x, sdf.multires, ev.w_sdf, None, None, 1)
+        A0d = ev._embed(x, ev.tr.multires, ev.w_def, ev.conds, bi, 1)
+        ref_s = me.forward(ev.sdf_spec, A0[:M].contiguous(), ev.sdf_W, ev.sdf_b, 1)
+        ref_d = me.forward(ev.tr.spec, A0d[:M].contiguous(), ev.def_W, ev.def_b, 1)
+        ws.a0[:P].copy_(A0); ws.a0d[:P].copy_(A0d)
+        for t in ws.sdf_act + ws.def_act:
+            t.fill_(float('nan'))
+        ws.live[0] = M
+        fwd = F._forward_chain(ws, ev)
+        fwd.m_mul, fwd.barrier, fwd.error, fwd.m_dev = 1, ws.sync.data_ptr(), ws.sync.data_ptr() + 4, ws.live.data_ptr()
+        _lib.call("sr_mlp_chain", ctypes.byref(fwd), _lib.stream_of(x))
+        torch.cuda.synchronize()
+        assert int(ws.sync[1]) == 0                          # the device-wide barrier never gave up
+        for a, b in zip(ws.sdf_act, ref_s):
+            assert torch.equal(a[:M, :b.shape[1]], b)        # bit-identical: same tile code, same k order
+            assert torch.isnan(a[M + 64:]).all()             # rows past the live count (beyond the last partial tile) untouched
+        for a, b in zip(ws.def_act, ref_d):
+            assert torch.equal(a[:M, :b.shape[1]], b)
+        # reverse chain == me.reverse (input gradients)
+        ones = ev.unit_cotangent(M)
+        tcot = fx.det_tensor((M, 4), 10, 1.0).to(DEV); tcot[:, 3] = 0
+        rs, _, _ = me.reverse(ev.sdf_spec, A0[:M].contiguous(), ev.sdf_WT, ref_s, ones, 1, True, False)
+        rd, _, _ = me.reverse(ev.tr.spec, A0d[:M].contiguous(), ev.def_WT, ref_d, tcot, 1, True, False)
+        ws.unit[:M].copy_(ones); ws.t[:M].copy_(tcot)
+        rev = F._reverse_chain(ws, ev)
+        rev.m_mul, rev.barrier, rev.error, rev.m_dev = 1, ws.sync.data_ptr(), ws.sync.data_ptr() + 4, ws.live.data_ptr()
+        _lib.call("sr_mlp_chain", ctypes.byref(rev), _lib.stream_of(x))
+        torch.cuda.synchronize()
+        assert int(ws.sync[1]) == 0
+        skip = ws.sdf_zbar[4][:M, 473:512]
+        got = ws.a0bar[:M].clone(); got[:, :39] += skip
+        assert torch.equal(got, rs) and torch.equal(ws.a0dbar[:M], rd)
+        ws.live[0] = 0                                       # no live rows: nothing is touched, nothing hangs
+        _lib.call("sr_mlp_chain", ctypes.byref(fwd), _lib.stream_of(x)); torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("P,times", [(5000, 10), (777, 3), (64, 10)])
+def test_device_driven_refiner_equals_the_layerwise_loop(P, times):
+    from selfreconcode_amd.utils import FindSurfacePs as F
+    sdf, comp = _nets()
+    N = 3
+    defconds = [fx.det_tensor((N, 128), 3, 0.1).to(DEV), [fx.det_tensor((N, 24, 3), 1, 0.1).to(DEV), fx.det_tensor((N, 3), 2, 0.05).to(DEV)]]
+    cam, rays, p0, bi = _rays(P, N)
+    # rays must hit where the DEFORMED point lies on the pixel ray: take the rays of the deformed seeds themselves
+    with torch.no_grad():
+        dseed = comp(p0.to(DEV), defconds, bi.to(DEV), ratio=RATIO).cpu()
+    rays = torch.nn.functional.normalize(dseed - cam, dim=1)
+    outs = []
+    for flag in (False, True, True):
+        F.DEVICE_DRIVEN = flag
+        p_in = p0.to(DEV).clone()
+        ps, ok = F.OptimizeSurfacePs(cam.to(DEV), rays.to(DEV), p_in, bi.to(DEV), sdf, RATIO, comp, defconds, dthreshold=5.e-5, athreshold=0.04,
+                                     w1=3.05, w2=1., times=times)
+        assert ps.data_ptr() == p_in.data_ptr() or torch.equal(ps, p_in)
+        outs.append((ps.cpu().clone(), ok.cpu().clone()))
+    F.DEVICE_DRIVEN = True
+    (pa, oa), (pb, ob), (pc, oc) = outs
+    assert torch.equal(pb, pc) and torch.equal(ob, oc)                       # deterministic although queue slots are claimed by atomics
+    assert (oa == ob).float().mean() > 0.995 and 0.3 < float(ob.float().mean())   # same flags up to threshold flips
+    same = oa == ob
+    torch.testing.assert_close(pb[same], pa[same], rtol=0, atol=2e-6)
+    if P == 5000:
+        assert 0.05 < float((~ob).float().mean()) or float(ob.float().mean()) > 0.9
