@@ -48,6 +48,9 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
     FR, RAYS = STAGES[stage]["frames"], STAGES[stage]["rays"]
     net, ds, conf = build_synthetic_scene(device=device, frame_num=64 if world <= 8 else 8 * world, stage=stage, consistent_masks=False)
     params = [p for p in net.parameters() if p.requires_grad]
+    net.refiner_stream = args.refiner_stream
+    from selfreconcode_amd.utils import FindSurfacePs as _fsp
+    _fsp.DEVICE_DRIVEN = args.refiner_impl == "device"
     mlp_engine.set_deferred_param_grads(True)              # one weight-norm backward + grad add per layer per step
     lr0 = conf.get_float('train.learning_rate')
     opt = torch.optim.Adam([{'params': ds.learnable_weights()}, {'params': params}], lr=lr0)
@@ -151,6 +154,8 @@ def main():
     ap.add_argument("--settle-low", type=int, default=40, help="untimed iterations at --lr before warm-up")
     ap.add_argument("--noise-observations", action="store_true", help="uniform-noise colour/normal targets instead of rendered ones (round-1 workload)")
     ap.add_argument("--no-fine", action="store_true", help="skip the fine-stage record of the default single-GPU run")
+    ap.add_argument("--refiner-stream", choices=["main", "side"], default="main", help="run the refiner after (main) or concurrently with (side) the template branch")
+    ap.add_argument("--refiner-impl", choices=["device", "layerwise"], default="device", help="device-driven compacting refiner or the layer-by-layer host loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true", help="skip the HIP-event pairs around the layer GEMMs (roofline leg) to see their cost")
     ap.add_argument("--shape-log", default=None, help="write the per-(M,N,K) GEMM launch table (events) to this JSON file")
@@ -200,6 +205,7 @@ def main():
                    "stage": args.stage, "frames_per_gpu": FR, "rays_per_frame": RAYS, "image": main_rec["image"], "template_vertices": V,
                    "rays_per_iter": main_rec["rays_per_iter"], "rays_converged_frac": main_rec["rays_converged_frac"],
                    "observations": "uniform noise" if args.noise_observations else "rendered from the scene (render_frames), re-rendered after the settle phase",
+                   "refiner": {"impl": args.refiner_impl, "stream": args.refiner_stream},
                    "optimizer": {"lr_timed": args.lr, "settle_iters_lr_1e-4": args.settle, "settle_iters_lr_timed": args.settle_low},
                    "rasterisation": "in-repo HIP kernels with pytorch3d 0.4.0 semantics (nearest-face mesh rasteriser -> FindSurfacePs; K=50 nearest-in-z "
                                     "point compositor); pytorch3d itself is third-party and not in the reference repository",
@@ -209,7 +215,7 @@ def main():
         "regime_lr_config": main_rec.get("regime_lr_config"),
         "fine_stage": fine_rec,
         "sdf_mlp_gsamples_per_s": round(sdf_gs, 5),
-        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (fp32 MFMA 32x32x2 layer GEMM with fused epilogue), EVERY launch of the timed region with >= 128 rows and > 32 columns; "
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel / mlp_chain_kernel (fp32 MFMA 32x32x2 layer GEMM tile code with fused epilogue; the chain kernel runs all layers of the refiner's two networks in one launch on the device-side live-ray count), EVERY launch of the timed region with >= 128 rows and > 32 columns and every chain launch; "
                                                 "launches issued while two streams feed the GPU are included (their event intervals can contain the other stream's kernels, "
                                                 "which only lowers the figure); `achieved_alone` restricts to the launches that had the GPU to themselves",
                      "achieved": prof.get("tflops_all", 0.0), "peak": 157.3, "unit": "TFLOP/s", "frac": round(prof.get("tflops_all", 0.0) / 157.3, 4),

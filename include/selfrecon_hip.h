@@ -125,13 +125,15 @@ typedef struct {
 } sr_gemm_args;
 int sr_mlp_gemm_nt(const sr_gemm_args* host_args, void* stream);
 
-/* Persistent layer chain: up to SR_CHAIN_MAX_LAYERS consecutive layer GEMMs of one or two independent networks in ONE
- * launch, on a row count read from device memory: rows = *m_dev * m_mul (every g[l][p].M is ignored; g[l][p].group must
- * equal m_mul).  Layer l+1 starts after a device-wide barrier behind layer l, so g[l+1][p].A may be g[l][p].C.
- * barrier: one uint32 of device scratch (zeroed by the call); error: int32 device flag, set to 1 if the barrier had to
- * give up (the grid -- 2 workgroups per CU -- must be resident at once), never cleared by the call.
- * This is the MLP half of the reference's utils/FindSurfacePs.py:129-162 loop body in two launches per Newton step
- * (forward chain, reverse chain) whatever the number of live rays is. */
+/* Layer chain: up to SR_CHAIN_MAX_LAYERS consecutive layer GEMMs of one or two independent networks (layer l of both side
+ * by side in one grid) on a row count read from DEVICE memory: rows = *m_dev * m_mul <= m_cap * m_mul (every g[l][p].M is
+ * ignored; g[l][p].group must equal m_mul).  g[l+1][p].A may be g[l][p].C.  Two forms:
+ *   persistent == 0 : one launch per layer, grids sized for m_cap, workgroups beyond the live tiles return at once;
+ *   persistent != 0 : ONE launch for the whole chain, layers separated by a device-wide barrier (barrier: one uint32 of
+ *                     device scratch, zeroed by the call; error: int32 device flag set to 1 if the barrier had to give up --
+ *                     the grid, 2 workgroups per CU, must be resident at once -- never cleared by the call).
+ * This is the MLP half of the reference's utils/FindSurfacePs.py:129-162 loop body on whatever number of rays is still
+ * unfinished, without the host ever learning that number. */
 #define SR_CHAIN_MAX_LAYERS 10
 typedef struct {
   int32_t nlayers;
@@ -139,6 +141,9 @@ typedef struct {
   sr_gemm_args g[SR_CHAIN_MAX_LAYERS][2];
   const int32_t* m_dev; int32_t m_mul;
   uint32_t* barrier; int32_t* error;
+  int32_t poll_mode;               /* how a waiting workgroup reads the arrival counter: 0 relaxed agent-scope load, 1 atomic read-modify-write */
+  int32_t m_cap;                   /* upper bound of *m_dev (sizes the grids of the per-layer form) */
+  int32_t persistent;
 } sr_chain_args;
 int sr_mlp_chain(const sr_chain_args* host_args, void* stream);
 
@@ -193,6 +198,11 @@ int sr_lbs_fwd(const sr_lbs_args* host_args, void* stream);
  * per-frame blend, model/Deformer.py:207-233): pbar = (dy/dp)^T ybar, Abar [nframes,24,12] += w_j ybar (x) [p;1],
  * transbar [nframes,3] += ybar.  Abar / transbar are accumulated (zero-fill first); each output is nullable. */
 int sr_lbs_bwd(const sr_lbs_args* host_args, const float* ybar, float* pbar, float* Abar, float* transbar, void* stream);
+/* Reverse sweep of sr_lbs_fwd WITH its Jacobian output: cotangents ybar [P,3] (nullable) and Jbar [P,3,3] of (y, jac) ->
+ * pbar (includes the mixed second derivatives of the trilinear sampler), Abar, transbar (accumulated as in sr_lbs_bwd).
+ * Backward of the value + Jacobian form of the deformer that replaces compute_Jacobian's three reverse passes with
+ * create_graph (utils/utils.py:106-120) in the colour / normal branch and in propagateTmpPsGrad. */
+int sr_lbs_jac_bwd(const sr_lbs_args* host_args, const float* ybar, const float* Jbar, float* pbar, float* Abar, float* transbar, void* stream);
 
 /* SMPL kinematic chain of LBSkinner.forward / posedSkeleton (model/Deformer.py:144-203, smpl_pytorch/util.py:35-78):
  * poses [B,24,3] axis-angle (device) -> G [B,24,4,4] posed chain and A = G * init_pose [B,24,4,4].
@@ -310,6 +320,11 @@ int sr_interp2x3d_fwd_f32(const float* in, int64_t BC, int32_t d, int32_t h, int
 int sr_interp2x3d_fwd_f64(const double* in, int64_t BC, int32_t d, int32_t h, int32_t w, float balance, double* out, uint8_t* is_boundary, void* stream);
 int sr_interp2x3d_bwd_f32(const float* grad_out, int64_t BC, int32_t d, int32_t h, int32_t w, float* grad_in, void* stream);
 int sr_interp2x3d_bwd_f64(const double* grad_out, int64_t BC, int32_t d, int32_t h, int32_t w, double* grad_in, void* stream);
+/* Candidate voxels of one Seg3dLossless level (MCAcc/seg3d_lossless.py:296-312: smooth_conv3x3(is_boundary) > 0, minus the
+ * voxels evaluated at earlier levels, nonzero) in one pass: out_index receives the flat indices z*H*W + y*W + x (capacity
+ * D*H*W entries, unordered), *count_dev their number (uint64, device).  is_boundary / done: [D,H,W] bytes (0 / non-0). */
+int sr_seg3d_candidates(const uint8_t* is_boundary, const uint8_t* done, int32_t D, int32_t H, int32_t W, int64_t* out_index, uint64_t* count_dev,
+                        void* stream);
 
 /* ---------------------------------------------------------------- rasterisation either side of the refiner
  * The reference calls pytorch3d 0.4.0 here (third-party CUDA, not in its repository; restated in oracle/raster_oracle.py,

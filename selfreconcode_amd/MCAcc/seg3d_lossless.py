@@ -89,16 +89,22 @@ class Seg3dLossless(nn.Module):
             nd[::2, ::2, ::2] = done                                             # evaluated voxels carry over (coords_accum *= 2)
             done = nd
             if self.use_cuda_impl:
+                # fused HIP path: 2x upsample + "parents disagree" flag (K10), then dilation + exclusion + compaction in one pass
                 from ..ext import interp2x_boundary3d
+                from .. import _lib
                 occ, bflag = interp2x_boundary3d.forward(occ.float().contiguous(), bal)
-                boundary = bflag.float()
+                cand = torch.empty(D * H * W, dtype=torch.int64, device=dev)
+                cnt = torch.empty(1, dtype=torch.int64, device=dev)
+                with torch.cuda.device(dev):
+                    _lib.call("sr_seg3d_candidates", _lib.ptr(bflag), _lib.ptr(done), D, H, W, _lib.ptr(cand), _lib.ptr(cnt), _lib.stream_of(occ))
+                idx = cand[:int(cnt)].sort().values                             # (one host sync, as nonzero; sorted = the reference's order)
             else:
                 valid = F.interpolate((occ > bal).float(), size=(D, H, W), mode="trilinear", align_corners=True)
                 occ = F.interpolate(occ.float(), size=(D, H, W), mode="trilinear", align_corners=True)
                 boundary = ((valid > 0.0) & (valid < 1.0)).float()
-            boundary = F.max_pool3d(boundary, kernel_size=3, stride=1, padding=1)[0, 0] > 0     # == smooth_conv3x3(.) > 0
-            boundary &= ~done
-            idx = boundary.view(-1).nonzero(as_tuple=False).view(-1)             # flat index z*H*W + y*W + x
+                boundary = F.max_pool3d(boundary, kernel_size=3, stride=1, padding=1)[0, 0] > 0     # == smooth_conv3x3(.) > 0
+                boundary &= ~done
+                idx = boundary.view(-1).nonzero(as_tuple=False).view(-1)         # flat index z*H*W + y*W + x
             if idx.numel() == 0:
                 continue
             flat = occ.view(-1)

@@ -54,7 +54,7 @@ SR_CHAIN_MAX_LAYERS = 10
 
 class SrChainArgs(ctypes.Structure):
     _fields_ = [("nlayers", ctypes.c_int32), ("nprob", ctypes.c_int32 * SR_CHAIN_MAX_LAYERS), ("g", (SrGemmArgs * 2) * SR_CHAIN_MAX_LAYERS),
-                ("m_dev", _vp), ("m_mul", ctypes.c_int32), ("barrier", _vp), ("error", _vp)]
+                ("m_dev", _vp), ("m_mul", ctypes.c_int32), ("barrier", _vp), ("error", _vp), ("poll_mode", ctypes.c_int32), ("m_cap", ctypes.c_int32), ("persistent", ctypes.c_int32)]
 
 
 class SrRefineArgs(ctypes.Structure):
@@ -115,6 +115,7 @@ SIGNATURES = {
     "sr_lbs_chain_bwd": [_vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sr_lbs_fwd": [_vp, _vp],
     "sr_lbs_bwd": [_vp, _vp, _vp, _vp, _vp, _vp],
+    "sr_lbs_jac_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sr_newton_update": [_vp, _vp],
     "sr_newton_prepare": [_vp, _vp],
     "sr_newton_apply": [_vp, _vp],
@@ -129,6 +130,7 @@ SIGNATURES = {
     "sr_interp2x3d_fwd_f64": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp],
     "sr_interp2x3d_bwd_f32": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
     "sr_interp2x3d_bwd_f64": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
+    "sr_seg3d_candidates": [_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp],
     "sr_rasterize_meshes": [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp],
     "sr_pe_embed_bwd": [_vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _i64, _vp, _vp],
     "sr_pe_embed": [_vp, _i64, ctypes.c_int32, _vp, _vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _i64, _vp],

@@ -113,7 +113,51 @@ int bwd(const T* go, int64_t BC, int d, int h, int w, T* gi, void* st) {
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// Seg3dLossless candidate selection (MCAcc/seg3d_lossless.py:296-312 of the reference: 3x3x3 box filter of the boundary
+// flags > 0, minus the voxels evaluated at earlier levels, then nonzero): one pass over the two byte volumes, the surviving
+// voxel indices are compacted by wave ballots (one atomicAdd per wave).  Output order is whatever the waves claim; the
+// caller's queries and scatter do not depend on it (it may sort the list for a reproducible order).
+namespace {
+__global__ __launch_bounds__(256) void seg3d_candidates_kernel(const uint8_t* __restrict__ bnd, const uint8_t* __restrict__ done, int D, int H, int W,
+                                                                int64_t* __restrict__ out, unsigned long long* __restrict__ count) {
+  const int64_t total = (int64_t)D * H * W;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < total; base += stride) {
+    const int64_t i = base + threadIdx.x;
+    bool keep = false;
+    if (i < total && !done[i]) {
+      const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)(i / ((int64_t)W * H));
+      for (int dz = -1; dz <= 1 && !keep; ++dz) {
+        const int zz = z + dz;
+        if (zz < 0 || zz >= D) continue;
+        for (int dy = -1; dy <= 1 && !keep; ++dy) {
+          const int yy = y + dy;
+          if (yy < 0 || yy >= H) continue;
+          const uint8_t* row = bnd + ((int64_t)zz * H + yy) * W;
+          keep = (x > 0 && row[x - 1]) || row[x] || (x + 1 < W && row[x + 1]);
+        }
+      }
+    }
+    const unsigned long long m = __ballot(keep);
+    const int lane = threadIdx.x & 63;
+    unsigned long long slot0 = 0;
+    if (lane == 0 && m) slot0 = atomicAdd(count, (unsigned long long)__popcll(m));
+    slot0 = __shfl(slot0, 0, 64);
+    if (keep) out[slot0 + __popcll(m & ((1ull << lane) - 1ull))] = i;
+  }
+}
+}  // namespace
+
 extern "C" {
+int sr_seg3d_candidates(const uint8_t* is_boundary, const uint8_t* done, int32_t D, int32_t H, int32_t W, int64_t* out_index, uint64_t* count_dev,
+                        void* stream) {
+  if (D <= 0 || H <= 0 || W <= 0 || !is_boundary || !done || !out_index || !count_dev) return SR_EINVAL;
+  if (hipMemsetAsync(count_dev, 0, 8, (hipStream_t)stream) != hipSuccess) return SR_ELAUNCH;
+  hipLaunchKernelGGL(seg3d_candidates_kernel, dim3(sr_stream_grid((int64_t)D * H * W, 256)), dim3(256), 0, (hipStream_t)stream, is_boundary, done, D, H, W,
+                     out_index, (unsigned long long*)count_dev);
+  return sr_launch_status();
+}
 int sr_interp2x3d_fwd_f32(const float* in, int64_t BC, int32_t d, int32_t h, int32_t w, float balance, float* out, uint8_t* is_boundary, void* s) { return fwd<float>(in, BC, d, h, w, balance, out, is_boundary, s); }
 int sr_interp2x3d_fwd_f64(const double* in, int64_t BC, int32_t d, int32_t h, int32_t w, float balance, double* out, uint8_t* is_boundary, void* s) { return fwd<double>(in, BC, d, h, w, balance, out, is_boundary, s); }
 int sr_interp2x3d_bwd_f32(const float* go, int64_t BC, int32_t d, int32_t h, int32_t w, float* gi, void* s) { return bwd<float>(go, BC, d, h, w, gi, s); }

@@ -161,7 +161,171 @@ __global__ __launch_bounds__(256) void lbs_bwd_kernel(sr_lbs_args g, const float
     else if (tbar) atomicAdd(tbar + f * 3 + (e - NJ * 12), v);
   }
 }
+
+// Backward of (y, J) = sr_lbs_fwd with its analytic Jacobian, for cotangents ybar [P,3] (nullable) and Jbar [P,3,3]:
+//   y = sum_j w_j v_j + t,  J = sum_j w_j A_j[:, :3] + sum_j v_j (x) grad w_j,   v_j = A_j [q;1],  w_j = trilinear sample at q.
+// With  e_j = <ybar, v_j> + <Jbar, A_j[:, :3]>  (cotangent of w_j)  and  gam_j = Jbar^T v_j  (cotangent of grad w_j):
+//   qbar  = T3^T ybar + sum_j A_j3^T (Jbar grad w_j) + sum_j e_j grad w_j + sum_j H_j gam_j      (H_j: mixed second derivatives
+//           of the trilinear interpolant, zero on the diagonal)
+//   Abar_j = (w_j ybar + Jbar grad w_j) (x) [q;1] + w_j [Jbar | 0],   tbar = ybar.
+// Two sweeps over the 8 corners (the second one hits the cache): the first rebuilds w_j and grad w_j, the joint loop between
+// them emits Abar and replaces (w, grad w) by (e, gam) in the same registers, the second contracts the corners with (e, gam).
+__global__ __launch_bounds__(256) void lbs_jac_bwd_kernel(sr_lbs_args g, const float* __restrict__ ybar, const float* __restrict__ Jbar,
+                                                           float* __restrict__ pbar, float* __restrict__ Abar, float* __restrict__ tbar) {
+  extern __shared__ float sacc[];                 // nframes * (24*12 + 3)
+  const int per = NJ * 12 + 3;
+  for (int i = threadIdx.x; i < g.nframes * per; i += blockDim.x) sacc[i] = 0.f;
+  __syncthreads();
+  const int64_t sH = (int64_t)g.W * NJ, sD = (int64_t)g.H * g.W * NJ;
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < g.P; base += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t idx = base + threadIdx.x;
+    if (idx < g.P) {
+      const float q[3] = {g.p[idx * 3], g.p[idx * 3 + 1], g.p[idx * 3 + 2]};
+      float yb[3] = {0.f, 0.f, 0.f}, Jb[9];
+      if (ybar) { yb[0] = ybar[idx * 3]; yb[1] = ybar[idx * 3 + 1]; yb[2] = ybar[idx * 3 + 2]; }
+#pragma unroll
+      for (int e = 0; e < 9; ++e) Jb[e] = Jbar[idx * 9 + e];
+      const Axis ax = make_axis(q[0], g.bmin[0], g.bmax[0], g.W);
+      const Axis ay = make_axis(q[1], g.bmin[1], g.bmax[1], g.H);
+      const Axis az = make_axis(q[2], g.bmin[2], g.bmax[2], g.D);
+      const int frame = g.batch_inds ? (int)g.batch_inds[idx] : (int)(idx / g.points_per_frame);
+      const float* Af = g.A + (int64_t)frame * NJ * 12;
+      float* acc = sacc + frame * per;
+      const bool full_wave = base + (int64_t)(threadIdx.x | 63) < g.P;
+      const bool uniform = full_wave && __all(frame == __builtin_amdgcn_readfirstlane(frame));
+      // The joints are processed in two halves of 12 (every sum over j is additive): half the coefficient registers, and each half
+      // reads only its own 48 bytes of a corner's 96-byte run.
+      float T[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, m[3] = {0.f, 0.f, 0.f};
+      float gu = 0.f, gv = 0.f, gw_ = 0.f;             // sum_j e_j grad_u w_j
+      float hxy_y = 0.f, hxy_x = 0.f, hxz_z = 0.f, hxz_x = 0.f, hyz_z = 0.f, hyz_y = 0.f;
+      constexpr int HJ = NJ / 2;
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        const int j0 = half * HJ;
+        // sweep 1: w_j and grad_u w_j
+        float c0[HJ], c1[HJ], c2[HJ], c3[HJ];
+#pragma unroll
+        for (int j = 0; j < HJ; ++j) { c0[j] = 0.f; c1[j] = 0.f; c2[j] = 0.f; c3[j] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+          const int x = ax.i0 + dx, y = ay.i0 + dy, z = az.i0 + dz;
+          if (x < 0 || x >= g.W || y < 0 || y >= g.H || z < 0 || z >= g.D) continue;
+          const float cx = dx ? ax.w1 : ax.w0, cy = dy ? ay.w1 : ay.w0, cz = dz ? az.w1 : az.w0;
+          const float wk = cx * cy * cz, gx = (dx ? 1.f : -1.f) * cy * cz, gy = (dy ? 1.f : -1.f) * cx * cz, gz = (dz ? 1.f : -1.f) * cx * cy;
+          const f32x4* src = reinterpret_cast<const f32x4*>(g.vol + z * sD + y * sH + (int64_t)x * NJ + j0);
+#pragma unroll
+          for (int v = 0; v < HJ / 4; ++v) {
+            const f32x4 c4 = src[v];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { c0[4 * v + e] += c4[e] * wk; c1[4 * v + e] += c4[e] * gx; c2[4 * v + e] += c4[e] * gy; c3[4 * v + e] += c4[e] * gz; }
+          }
+        }
+        // joint loop: T3, m = sum_j A_j3^T (Jbar grad w_j), Abar; then (w, grad w) -> (e, gam)
+#pragma unroll
+        for (int j = 0; j < HJ; ++j) {
+          const float* a = Af + (j0 + j) * 12;
+          const float wj = c0[j];
+          const float gw[3] = {c1[j] * ax.du, c2[j] * ay.du, c3[j] * az.du};        // grad_q w_j
+          float u[3], v3[3];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            v3[r] = a[r * 4] * q[0] + a[r * 4 + 1] * q[1] + a[r * 4 + 2] * q[2] + a[r * 4 + 3];
+            const float jg = Jb[r * 3] * gw[0] + Jb[r * 3 + 1] * gw[1] + Jb[r * 3 + 2] * gw[2];   // (Jbar grad w_j)_r
+            u[r] = wj * yb[r] + jg;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { T[r * 3 + c] += wj * a[r * 4 + c]; m[c] += a[r * 4 + c] * jg; }
+          }
+          if (Abar) {
+            float* o = acc + (j0 + j) * 12;
+            float c12[12];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+              for (int c = 0; c < 3; ++c) c12[r * 4 + c] = u[r] * q[c] + wj * Jb[r * 3 + c];
+              c12[r * 4 + 3] = u[r];
+            }
+            if (uniform) {
+#pragma unroll
+              for (int e = 0; e < 12; ++e) {
+                const float v = wave_sum(c12[e]);
+                if ((threadIdx.x & 63) == 0) atomicAdd(o + e, v);
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 12; ++e) atomicAdd(o + e, c12[e]);
+            }
+          }
+          float ej = yb[0] * v3[0] + yb[1] * v3[1] + yb[2] * v3[2];
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ej += Jb[r * 3 + c] * a[r * 4 + c];
+          c0[j] = ej;
+          c1[j] = Jb[0] * v3[0] + Jb[3] * v3[1] + Jb[6] * v3[2];                    // gam_j = Jbar^T v_j
+          c2[j] = Jb[1] * v3[0] + Jb[4] * v3[1] + Jb[7] * v3[2];
+          c3[j] = Jb[2] * v3[0] + Jb[5] * v3[1] + Jb[8] * v3[2];
+        }
+        if (pbar) {
+          // sweep 2: contract the corners with (e, gam)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+            const int x = ax.i0 + dx, y = ay.i0 + dy, z = az.i0 + dz;
+            if (x < 0 || x >= g.W || y < 0 || y >= g.H || z < 0 || z >= g.D) continue;
+            const float cx = dx ? ax.w1 : ax.w0, cy = dy ? ay.w1 : ay.w0, cz = dz ? az.w1 : az.w0;
+            const float sx = dx ? 1.f : -1.f, sy = dy ? 1.f : -1.f, sz = dz ? 1.f : -1.f;
+            const f32x4* src = reinterpret_cast<const f32x4*>(g.vol + z * sD + y * sH + (int64_t)x * NJ + j0);
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+            for (int v = 0; v < HJ / 4; ++v) {
+              const f32x4 c4 = src[v];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { d0 += c4[e] * c0[4 * v + e]; d1 += c4[e] * c1[4 * v + e]; d2 += c4[e] * c2[4 * v + e]; d3 += c4[e] * c3[4 * v + e]; }
+            }
+            gu += d0 * sx * cy * cz; gv += d0 * cx * sy * cz; gw_ += d0 * cx * cy * sz;
+            const float mxy = sx * sy * cz, mxz = sx * cy * sz, myz = cx * sy * sz;     // mixed second derivatives of the corner weight
+            hxy_y += mxy * d2; hxy_x += mxy * d1; hxz_z += mxz * d3; hxz_x += mxz * d1; hyz_z += myz * d3; hyz_y += myz * d2;
+          }
+        }
+      }
+      if (tbar && ybar) {
+        if (uniform) {
+          const float sx = wave_sum(yb[0]), sy = wave_sum(yb[1]), sz = wave_sum(yb[2]);
+          if ((threadIdx.x & 63) == 0) { atomicAdd(acc + NJ * 12, sx); atomicAdd(acc + NJ * 12 + 1, sy); atomicAdd(acc + NJ * 12 + 2, sz); }
+        } else {
+          atomicAdd(acc + NJ * 12, yb[0]); atomicAdd(acc + NJ * 12 + 1, yb[1]); atomicAdd(acc + NJ * 12 + 2, yb[2]);
+        }
+      }
+      if (pbar) {
+        pbar[idx * 3 + 0] = T[0] * yb[0] + T[3] * yb[1] + T[6] * yb[2] + m[0] + ax.du * (gu + ay.du * hxy_y + az.du * hxz_z);
+        pbar[idx * 3 + 1] = T[1] * yb[0] + T[4] * yb[1] + T[7] * yb[2] + m[1] + ay.du * (gv + ax.du * hxy_x + az.du * hyz_z);
+        pbar[idx * 3 + 2] = T[2] * yb[0] + T[5] * yb[1] + T[8] * yb[2] + m[2] + az.du * (gw_ + ax.du * hxz_x + ay.du * hyz_y);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < g.nframes * per; i += blockDim.x) {
+    const int f = i / per, e = i % per;
+    const float v = sacc[i];
+    if (v == 0.f) continue;
+    if (e < NJ * 12) { if (Abar) atomicAdd(Abar + (int64_t)f * NJ * 12 + e, v); }
+    else if (tbar) atomicAdd(tbar + f * 3 + (e - NJ * 12), v);
+  }
+}
 }  // namespace
+
+extern "C" int sr_lbs_jac_bwd(const sr_lbs_args* a, const float* ybar, const float* Jbar, float* pbar, float* Abar, float* transbar, void* stream) {
+  if (!a || a->P < 0 || a->nframes <= 0 || a->nframes > 32 || a->D <= 0 || a->H <= 0 || a->W <= 0) return SR_EINVAL;
+  if (a->P == 0) return SR_OK;
+  if (!a->p || !a->A || !a->vol || !Jbar || a->tp || ((uintptr_t)a->vol & 15)) return SR_EINVAL;
+  if (!a->batch_inds && a->points_per_frame <= 0) return SR_EINVAL;
+  int grid = sr_stream_grid(a->P, 256);
+  if (grid > 512) grid = 512;
+  const size_t lds = (size_t)a->nframes * (NJ * 12 + 3) * sizeof(float);
+  hipLaunchKernelGGL(lbs_jac_bwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, *a, ybar, Jbar, pbar, Abar, transbar);
+  return sr_launch_status();
+}
 
 extern "C" int sr_lbs_fwd(const sr_lbs_args* a, void* stream) {
   if (!a || a->P < 0 || a->nframes <= 0 || a->D <= 0 || a->H <= 0 || a->W <= 0) return SR_EINVAL;

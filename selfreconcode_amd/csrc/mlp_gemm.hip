@@ -426,22 +426,26 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
 // device-wide barrier before the next layer reads what this one wrote.  Written for the ray refiner, whose batch shrinks
 // from step to step (the live count is produced by the compaction kernel of the previous step and never visits the host)
 // and whose ~6k rows make a layer too short to amortise a launch: 14 + 14 layer launches per Newton step become 2.
-__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t target, int32_t* error) {
+__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t target, int32_t* error, int poll_mode) {
   __syncthreads();
   bool ok = true;
   if (threadIdx.x == 0) {
-    __threadfence();                                   // release: this workgroup's stores (made visible to thread 0 by the barrier above)
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // ONE release (write back this XCD's L2) before the arrival and ONE acquire (invalidate it) after the wait.  The polls in
+    // between are relaxed: an acquire load invalidates the L2 every time it is issued, under the feet of the workgroups of
+    // the same XCD that are still computing tiles of this layer (measured: the chain ran 4x slower that way).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     long long spins = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1ll << 24) || __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {   // a workgroup never arrived
-        __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                          // (grid not co-resident): give up
+    while ((poll_mode ? __hip_atomic_fetch_add(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                      : __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+      if (poll_mode) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(16);
+      if (++spins > (1ll << 23)) {                     // a workgroup never arrived (grid not co-resident): give up, loudly
+        __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = false;
         break;
       }
     }
-    __threadfence();                                   // acquire for the whole workgroup (through the barrier below)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   ok = __syncthreads_and(ok);
   return ok;
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(ChainCfg::kThreads) __attribute__((amdgpu_waves_per
       gemm_nt_tile<2, 2, 1, 1>(g, t - (p ? ntiles[0] : 0), smem);
       __syncthreads();                                 // the next tile reuses the LDS image
     }
-    if (l + 1 < c.nlayers && !grid_barrier(c.barrier, (uint32_t)(l + 1) * gridDim.x, c.error)) return;
+    if (l + 1 < c.nlayers && !grid_barrier(c.barrier, (uint32_t)(l + 1) * gridDim.x, c.error, c.poll_mode)) return;
   }
 }
 
@@ -738,6 +742,22 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
   return sr_launch_status();
 }
 
+// The same layer pair as ONE ordinary launch: grid sized for the capacity row count, workgroups past the tiles of the LIVE row count
+// (device memory) return at once.  No barrier, no residency requirement; consecutive layers are ordered by the stream.
+__global__ __launch_bounds__(ChainCfg::kThreads) __attribute__((amdgpu_waves_per_eu(2))) void mlp_layer_pair_kernel(sr_gemm_args g0, sr_gemm_args g1, int nprob,
+                                                                                                                     const int32_t* __restrict__ m_dev, int m_mul) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int M = *m_dev * m_mul;
+  if (M <= 0) return;
+  const int rows = (M + ChainCfg::BM - 1) / ChainCfg::BM;
+  const int t0 = rows * ((g0.N + (g0.mode == SR_EPI_FWD ? g0.naux_fwd : 0) + ChainCfg::BN - 1) / ChainCfg::BN);
+  const int t1 = nprob > 1 ? rows * ((g1.N + (g1.mode == SR_EPI_FWD ? g1.naux_fwd : 0) + ChainCfg::BN - 1) / ChainCfg::BN) : 0;
+  const int t = blockIdx.x;
+  if (t >= t0 + t1) return;
+  if (t < t0) { g0.M = M; gemm_nt_tile<2, 2, 1, 1>(g0, t, smem); }
+  else { g1.M = M; gemm_nt_tile<2, 2, 1, 1>(g1, t - t0, smem); }
+}
+
 static int chain_grid_size() {
   static int grid = 0;
   if (!grid) {
@@ -762,6 +782,22 @@ int sr_mlp_chain(const sr_chain_args* a, void* stream) {
       if (g.mode == SR_EPI_BWD && g.naux_fwd != 0) return SR_EINVAL;
       if ((g.mode == SR_EPI_BWD && g.act != SR_ACT_NONE && !g.aux) || (g.mode == SR_EPI_FWD && g.naux_fwd > 0 && !g.aux)) return SR_EINVAL;
     }
+  }
+  if (!a->persistent) {
+    // one launch per layer (pair): measured 12.6 us per dependent launch against ~35 us per device-wide barrier of the persistent
+    // form (512 workgroups each writing back and invalidating their XCD's L2), see profiles/r02_chain_bench.txt
+    if (a->m_cap <= 0) return SR_EINVAL;
+    const int64_t rows = sr_cdiv((int64_t)a->m_cap * a->m_mul, ChainCfg::BM);
+    for (int l = 0; l < a->nlayers; ++l) {
+      int64_t tiles = 0;
+      for (int p = 0; p < a->nprob[l]; ++p) {
+        const sr_gemm_args& g = a->g[l][p];
+        tiles += rows * sr_cdiv(g.N + (g.mode == SR_EPI_FWD ? g.naux_fwd : 0), ChainCfg::BN);
+      }
+      hipLaunchKernelGGL(mlp_layer_pair_kernel, dim3((unsigned)tiles), dim3(ChainCfg::kThreads), ChainCfg::kLdsFloats * sizeof(float), (hipStream_t)stream,
+                         a->g[l][0], a->g[l][a->nprob[l] > 1 ? 1 : 0], a->nprob[l], a->m_dev, a->m_mul);
+    }
+    return sr_launch_status();
   }
   const int grid = chain_grid_size();
   if (grid <= 0) return SR_ELAUNCH;

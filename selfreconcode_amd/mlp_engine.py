@@ -86,6 +86,7 @@ class _GemmProfile:
         inside the measured region a pair costs two hipEventRecord calls and nothing else."""
         self.enabled = enabled
         self.records = []
+        self.chains = []          # persistent layer-chain launches of the refiner: ([(e0, e1, phase, flop per row)], live counts, overlap flag)
         self.pool = []
         for _ in range(reserve if enabled else 0):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -99,6 +100,11 @@ class _GemmProfile:
         if not self.records:
             return {"tflops": 0.0, "launches": 0, "avg_us": 0.0, "avg_flop": 0.0}
         torch.cuda.synchronize()
+        for marks, live, overlap in self.chains:          # fold the chain launches in as records: FLOPs from the device-side row counts
+            lv = live.tolist()
+            for e0, e1, phase, fpr in marks:
+                self.records.append((e0, e1, fpr * lv[phase], lv[phase], overlap, (0, 0, "chain", 1)))
+        self.chains = []
         times = [r[0].elapsed_time(r[1]) for r in self.records]
 
         def rate(sel):

@@ -356,6 +356,69 @@ class _FusedLBS(torch.autograd.Function):
         return None, pbar, Abar, tbar, None, None
 
 
+class _LBSValueJacobian(torch.autograd.Function):
+    """(y, J) = (LBS(q), dLBS/dq) from the fused kernel with its analytic Jacobian; first-order differentiable with respect to
+    q, the posed transforms A and the translations through sr_lbs_jac_bwd (which carries the mixed second derivatives of the
+    trilinear weight lookup)."""
+
+    @staticmethod
+    def forward(ctx, skin, q, A, trans, batch_inds, ppf):
+        flat = q.reshape(-1, 3).contiguous().float()
+        y, J = skin.fused(flat if batch_inds is not None else flat.view(A.shape[0], -1, 3), A, trans, batch_inds, True, None)
+        ctx.skin, ctx.ppf = skin, ppf
+        ctx.save_for_backward(flat, A, batch_inds)
+        ctx.set_materialize_grads(False)
+        return y.reshape(-1, 3), J
+
+    @staticmethod
+    def backward(ctx, ybar, Jbar):
+        flat, A, batch_inds = ctx.saved_tensors
+        skin = ctx.skin
+        if ybar is None and Jbar is None:
+            return (None,) * 6
+        need_q, need_A, need_t = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        P = flat.shape[0]
+        a = _lib.SrLbsArgs()
+        A12 = A[:, :, :3, :].contiguous()
+        vol = skin.ws.permute(0, 2, 3, 4, 1)
+        a.p, a.tp, a.P = _lib.ptr(flat), 0, P
+        a.A, a.trans, a.nframes = _lib.ptr(A12), 0, A.shape[0]
+        a.batch_inds, a.points_per_frame = _lib.ptr(batch_inds), ctx.ppf
+        a.vol, a.D, a.H, a.W = _lib.ptr(vol), vol.shape[1], vol.shape[2], vol.shape[3]
+        box = skin._box_consts()
+        for i in range(3):
+            a.bmin[i], a.bmax[i] = box[0][i], box[1][i]
+        yb = None if ybar is None else ybar.contiguous().float()
+        Jb = torch.zeros((P, 3, 3), device=flat.device) if Jbar is None else Jbar.contiguous().float()
+        qbar = torch.empty_like(flat) if need_q else None
+        Abar = torch.zeros((A.shape[0], 24, 12), device=flat.device) if need_A else None
+        tbar = torch.zeros((A.shape[0], 3), device=flat.device) if (need_t and yb is not None) else None
+        with torch.cuda.device(flat.device):
+            _lib.call("sr_lbs_jac_bwd", ctypes.byref(a), _lib.ptr(yb), _lib.ptr(Jb), _lib.ptr(qbar), _lib.ptr(Abar), _lib.ptr(tbar), _lib.stream_of(flat))
+        if Abar is not None:
+            Abar = torch.nn.functional.pad(Abar.view(A.shape[0], 24, 3, 4), (0, 0, 0, 1))
+        return None, qbar, Abar, tbar, None, None
+
+
+def deformer_value_jacobian(deformer, ps, defconds, batch_inds, ratio):
+    """(d, J) = (d(p), dd/dp) of CompositeDeformer([MLPTranslator, LBSkinner]) for flat points with batch indices, by forward mode:
+    one group-4 pass of the deformation MLP (value + three seed tangents), the fused LBS kernel with its analytic Jacobian and one
+    3x3 product -- instead of a forward plus the three create_graph reverse passes of utils/utils.py:106-120 (compute_Jacobian)
+    through both stages.  First-order differentiable in everything the reference's graph reaches (points, MLP weights, per-frame
+    codes, poses, translations): what the colour / normal losses (network.py:599-639) and propagateTmpPsGrad (:702-814) need."""
+    tr, skin = deformer.defs[0], deformer.defs[1]
+    d_cond, (poses, trans) = defconds[0], defconds[1]
+    q, Jq = translator_value_jacobian(tr, ps, d_cond, batch_inds, ratio)
+    A = skin.posed_transforms(poses)
+    y, Jl = _LBSValueJacobian.apply(skin, q, A, trans, batch_inds, 0)
+    return y, torch.bmm(Jl, Jq)
+
+
+def is_fused_composite(deformer):
+    return (isinstance(deformer, CompositeDeformer) and deformer.N == 2 and isinstance(deformer.defs[0], MLPTranslator)
+            and isinstance(deformer.defs[1], LBSkinner))
+
+
 class TranslatorValueJacobian(torch.autograd.Function):
     """(d, J) = (p + offset(p), I + d offset / d p) of the deformation MLP by FORWARD mode: one group-4 pass of
     the layer kernels (primal + 3 seed tangents per point) instead of a forward plus three reverse passes

@@ -276,7 +276,7 @@ def build_synthetic_scene(device="cuda:0", frame_num=64, H=540, W=540, stage="co
     rend = RenderingNetwork_view_norm(conf.get_int('render_net.condlen'), 'idr', 9, 3, [512, 512, 512, 512], True,
                                       multires_n=conf.get_int('render_net.multires_n'), multires_v=conf.get_int('render_net.multires_v')).to(device)
     engine = Seg3dLossless(query_func=None, b_min=LBS_BMIN, b_max=LBS_BMAX, resolutions=resolutions or STAGE_RESOLUTIONS[stage],
-                           align_corners=False, balance_value=0.0).to(device)
+                           align_corners=False, balance_value=0.0, use_cuda_impl=True).to(device)     # fused HIP upsample + candidate selection (same volume, same queries)
     net = OptimNetwork(sdf, deformer, engine, None, rend, conf=conf.get_config('loss_' + stage)).to(device)
     net.remesh_intersect = conf.get_int(f'train.{stage}.point_render.remesh_intersect')
     net.point_radius = conf.get_float(f'train.{stage}.point_render.radius')

@@ -154,9 +154,12 @@ def _newton(ev, x, bi, rays, cam, group, dthr, athr, w1, w2, update):
 
 # ------------------------------------------------------------------------------------------------
 # Device-driven refiner: the queue of unfinished rays, its compaction and every row count stay on the GPU
-# (csrc/refiner.hip + the persistent layer chains of csrc/mlp_gemm.hip); the host issues a FIXED sequence of
-# 3 + 5*times + 3 launches per call and never synchronises.
+# (csrc/refiner.hip + the layer chains of csrc/mlp_gemm.hip); the host issues a FIXED sequence of launches per call
+# (3 small kernels + 2 chains per Newton step) and never synchronises.
 DEVICE_DRIVEN = True
+CHAIN_PERSISTENT = __import__("os").environ.get("SR_CHAIN_PERSISTENT", "0") == "1"   # whole chain in one launch behind device-wide barriers
+                                                                                   # (56 launches per call instead of ~230, but slower: see DESIGN.md)
+CHAIN_POLL_MODE = int(__import__("os").environ.get("SR_CHAIN_POLL", "0"))     # tuning switch of the chain kernel's device-wide barrier
 _WORKSPACES = {}     # (device, capacity) -> _RefinerWorkspace
 _ERROR_WATCH = {}    # device -> (pinned int32, event) of the previous call's barrier-failure flag
 
@@ -279,26 +282,42 @@ def _optimize_device_driven(ev, cam, rays, initTmpPs, batch_inds, dthreshold, at
     a.p_out, a.conv_out = _lib.ptr(p_out), _lib.ptr(conv_out)
     fwd, rev = _forward_chain(ws, ev), _reverse_chain(ws, ev)
     for c in (fwd, rev):
-        c.m_mul, c.barrier, c.error = 1, ws.sync.data_ptr(), ws.sync.data_ptr() + 4
+        c.m_mul, c.barrier, c.error, c.poll_mode = 1, ws.sync.data_ptr(), ws.sync.data_ptr() + 4, CHAIN_POLL_MODE
+        c.m_cap, c.persistent = P, 1 if CHAIN_PERSISTENT else 0
     with torch.cuda.device(dev):
         st = _lib.stream_of(x0)
         ra = ctypes.byref(a)
         _lib.call("sr_refine_init", ra, st)
 
+        prof = me.PROFILE if me.PROFILE.enabled else None
+        fwd_flop = sum(2.0 * g.N * g.K for l in range(fwd.nlayers) for g in fwd.g[l][:fwd.nprob[l]])
+        rev_flop = sum(2.0 * g.N * g.K for l in range(rev.nlayers) for g in rev.g[l][:rev.nprob[l]])
+        marks = []
+
+        def chain(c, phase, flop_per_row):
+            c.m_dev = ws.live.data_ptr() + 4 * phase
+            if prof is not None:                           # bench.py's roofline leg: the chain's FLOPs are live[phase] x (sum over its layers)
+                e0, e1 = prof.pair()
+                e0.record()
+            _lib.call("sr_mlp_chain", ctypes.byref(c), st)
+            if prof is not None:
+                e1.record()
+                marks.append((e0, e1, phase, flop_per_row))
+
         def evaluate(phase):
             _lib.call("sr_refine_embed", ra, phase, st)
-            fwd.m_dev = ws.live.data_ptr() + 4 * phase
-            _lib.call("sr_mlp_chain", ctypes.byref(fwd), st)
+            chain(fwd, phase, fwd_flop)
         evaluate(0)
         _lib.call("sr_refine_mid", ra, 0, 0, st)
         for k in range(1, times + 1):
             evaluate(k)
             _lib.call("sr_refine_mid", ra, k, 1, st)
-            rev.m_dev = ws.live.data_ptr() + 4 * k
-            _lib.call("sr_mlp_chain", ctypes.byref(rev), st)
+            chain(rev, k, rev_flop)
             _lib.call("sr_refine_finish", ra, k, st)
         evaluate(times + 1)
         _lib.call("sr_refine_mid", ra, times + 1, 2, st)
+        if prof is not None:
+            prof.chains.append((marks, ws.live[:times + 2].clone(), me.PROFILE.overlap))
         ws.pinned_err.copy_(ws.sync[1:2], non_blocking=True)
         e = torch.cuda.Event(); e.record()
         _ERROR_WATCH[dev] = (ws.pinned_err, e)

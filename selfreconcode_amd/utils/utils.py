@@ -105,6 +105,23 @@ def compute_Jacobian(ps, ds, retain_graph, create_graph, allow_unused=False):
     return torch.cat(grad_d_p, dim=1)
 
 
+FORWARD_MODE_JACOBIAN = True    # deformer value + Jacobian by one forward-mode pass (model/Deformer.py::deformer_value_jacobian)
+
+
+def deformed_points_and_jacobian(deformer, ps, defconds, batch_inds, ratio, differentiable):
+    """d(p) and dd/dp (utils.py:106-120 applied to the deformer): the fused forward-mode Function when the deformer is this
+    package's MLPTranslator + LBSkinner composite and the points come with batch indices, the generic three reverse passes
+    otherwise.  `differentiable`: the caller will back-propagate through the result (the 'train' phase)."""
+    from ..model.Deformer import is_fused_composite, deformer_value_jacobian
+    if FORWARD_MODE_JACOBIAN and batch_inds is not None and ps.dim() == 2 and is_fused_composite(deformer):
+        if differentiable:
+            return deformer_value_jacobian(deformer, ps, defconds, batch_inds, ratio)
+        with torch.no_grad():
+            return deformer_value_jacobian(deformer, ps, defconds, batch_inds, ratio)
+    ds = deformer(ps, defconds, batch_inds, ratio=ratio)
+    return ds, compute_Jacobian(ps, ds, differentiable, differentiable)
+
+
 def compute_deformed_normals(sdf, deformer, ps, defconds, batch_inds, ratio, phase, cache=None, onx=None):
     """utils/utils.py:132-153.
 
@@ -122,8 +139,7 @@ def compute_deformed_normals(sdf, deformer, ps, defconds, batch_inds, ratio, pha
     if cache is not None and 'J' in cache and not check:
         ds, grad_d_p = cache['ds'].detach(), cache['J'].detach()
     else:
-        ds = deformer(ps, defconds, batch_inds, ratio=ratio)
-        grad_d_p = compute_Jacobian(ps, ds, check, check)
+        ds, grad_d_p = deformed_points_and_jacobian(deformer, ps, defconds, batch_inds, ratio, check)
     grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
     nx = grad_d_p_inv.transpose(-2, -1).matmul(onx.view(-1, 3, 1)).view(-1, 3)
     # singular Jacobians fall back to J n (reference :145-150).  The reference tests the mask on the host and prints a warning
@@ -141,8 +157,7 @@ def compute_cardinal_rays(deformer, ps, rays, defconds, batch_inds, ratio, phase
     if cache is not None and 'J' in cache:
         ds, grad_d_p = cache['ds'], cache['J']
     else:
-        ds = deformer(ps, defconds, batch_inds, ratio=ratio)
-        grad_d_p = compute_Jacobian(ps, ds, check, check)
+        ds, grad_d_p = deformed_points_and_jacobian(deformer, ps, defconds, batch_inds, ratio, check)
         if cache is not None:
             cache['ds'], cache['J'] = ds, grad_d_p
     grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)

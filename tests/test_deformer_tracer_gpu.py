@@ -183,3 +183,64 @@ def test_refiner_forward_and_reverse_mode_agree(golden):
     close(outs[0][0], outs[1][0], rtol=0, atol=1e-5)
     close(outs[1][0], g["ps"], rtol=0, atol=2e-5)
     assert (outs[0][1] == outs[1][1]).float().mean() > 0.97
+
+
+@pytest.mark.parametrize("interleaved", [False, True])
+def test_forward_mode_deformer_value_jacobian_equals_the_reverse_mode_graph(interleaved):
+    """deformer_value_jacobian (group-4 translator pass + fused LBS with analytic Jacobian + sr_lbs_jac_bwd) against the generic
+    path it replaces in the colour / normal branch: deformer() + compute_Jacobian with create_graph (three reverse passes through
+    the MLP and the differentiable LBS composition, second order through the HIP sampler's double backward).  Value, Jacobian and
+    the gradient of a scalar of (d, J) with respect to points, MLP weights, per-frame codes, poses and translations."""
+    from selfreconcode_amd.model.Deformer import deformer_value_jacobian
+    from selfreconcode_amd.utils.utils import compute_Jacobian
+    comp = _composite(last_scale=0.3)
+    N, P = 3, 900
+    p0 = (fx.det_tensor((P, 3), 31, 1.0) * torch.tensor([0.7, 1.0, 0.35])).to(DEV)
+    p0[:5, 0] = 0.95                                                   # a few points outside the skinning-weight box (border rule: zero sampler gradient)
+    bi = (torch.arange(P) % N if interleaved else (torch.arange(P) * N) // P).to(DEV)
+    wy, wJ = fx.det_tensor((P, 3), 32, 1.0).to(DEV), fx.det_tensor((P, 3, 3), 33, 1.0).to(DEV)
+    outs = []
+    for fused in (False, True):
+        cond = (fx.det_tensor((N, 128), 3, 0.1)).to(DEV).requires_grad_(True)
+        poses = fx.det_tensor((N, 24, 3), 1, 0.15).to(DEV).requires_grad_(True)
+        trans = fx.det_tensor((N, 3), 2, 0.05).to(DEV).requires_grad_(True)
+        p = p0.clone().requires_grad_(True)
+        defconds = [cond, [poses, trans]]
+        if fused:
+            d, J = deformer_value_jacobian(comp, p, defconds, bi, RATIO)
+        else:
+            d = comp(p, defconds, bi, ratio=RATIO)
+            J = compute_Jacobian(p, d, True, True)
+        s = (d * wy).sum() + (J * wJ).sum()
+        tr = comp.defs[0]
+        g = torch.autograd.grad(s, [p, tr.lin0.weight, tr.lin2.weight, tr.lin4.weight, tr.lin4.bias, cond, poses, trans])
+        outs.append((d.detach(), J.detach(), g))
+    (d0, J0, g0), (d1, J1, g1) = outs
+    close(d1, d0, 1e-5, 2e-6); close(J1, J0, 1e-4, 1e-5)
+    for name, a, b in zip(("p", "lin0.w", "lin2.w", "lin4.w", "lin4.b", "cond", "poses", "trans"), g1, g0):
+        torch.testing.assert_close(a.cpu(), b.cpu(), rtol=2e-3, atol=2e-3 * max(1e-6, float(b.abs().max())), msg=lambda m, name=name: name + ": " + m)
+
+
+def test_lbs_jacobian_backward_against_float64_autograd():
+    """sr_lbs_jac_bwd alone: cotangents on (y, J) of the fused LBS kernel against float64 autograd of the oracle's LBS + its
+    autograd Jacobian (incl. the mixed second derivatives of the trilinear weights)."""
+    from selfreconcode_amd.model.Deformer import _LBSValueJacobian
+    skin = _skinner((9, 13, 11))
+    N, P = 2, 400
+    q = (fx.det_tensor((P, 3), 41, 1.0) * torch.tensor([0.6, 0.9, 0.3]))
+    bi = (torch.arange(P) * N) // P
+    poses = fx.det_tensor((N, 24, 3), 1, 0.2); trans = fx.det_tensor((N, 3), 2, 0.05)
+    wy, wJ = fx.det_tensor((P, 3), 42, 1.0), fx.det_tensor((P, 3, 3), 43, 1.0)
+    qg = q.to(DEV).requires_grad_(True); pg = poses.to(DEV).requires_grad_(True); tg = trans.to(DEV).requires_grad_(True)
+    A = skin.posed_transforms(pg)
+    y, J = _LBSValueJacobian.apply(skin, qg, A, tg, bi.to(DEV), 0)
+    g = torch.autograd.grad((y * wy.to(DEV)).sum() + (J * wJ.to(DEV)).sum(), [qg, pg, tg])
+    kw = dict(ws=fx.synthetic_lbs_volume((9, 13, 11)).double(), b_min=torch.tensor(fx.LBS_BMIN).double(), b_max=torch.tensor(fx.LBS_BMAX).double(),
+              Js=fx.synthetic_joints().double(), init_pose=skin.init_pose.cpu().double())
+    qo = q.double().requires_grad_(True); po = poses.double().requires_grad_(True); to = trans.double().requires_grad_(True)
+    yo = orc.lbs_forward(qo, po, to, batch_inds=bi, **kw)
+    Jo = orc.compute_jacobian(qo, yo, True, True)
+    go = torch.autograd.grad((yo * wy.double()).sum() + (Jo * wJ.double()).sum(), [qo, po, to])
+    close(y, yo.float(), 1e-5, 2e-6); close(J, Jo.float(), 1e-4, 1e-5)
+    for name, a, b in zip(("q", "poses", "trans"), g, go):
+        torch.testing.assert_close(a.cpu(), b.float(), rtol=1e-3, atol=1e-3 * float(b.abs().max()), msg=lambda m, name=name: name + ": " + m)

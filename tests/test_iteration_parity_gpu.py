@@ -145,7 +145,10 @@ def test_whole_iteration_with_injected_randoms_vs_oracle():
         for k, v in (('mask_loss', i['pc_loss']['mask_loss']), ('defconst_loss', i['pc_loss']['defconst_loss']), ('pc_loss_sdf', i['pc_loss_sdf']),
                      ('grad_loss', i['grad_loss']), ('def_loss', i['def_loss']), ('dct_loss', i['dct_loss']), ('color_loss', i['color_loss']),
                      ('normal_loss', i['normal_loss'])):
-            close(v, info[k], 2e-4, 2e-4, k)
+            if k == 'pc_loss_sdf':                           # mean |f| of vertices that sit on the zero set: the value tolerance of f itself
+                torch.testing.assert_close(v.cpu(), info[k], rtol=2e-4, atol=2e-6)
+            else:
+                close(v, info[k], 2e-4, 2e-4, k)
         close(loss, tot, 2e-4, 2e-4, "total loss")
         tot.backward()
         n_sys, n_ok = ito.propagate(sc, st, fo, RATIO)

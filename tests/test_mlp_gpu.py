@@ -256,7 +256,7 @@ def test_sdf_forward_backward_at_96k_rows_vs_fp64():
     lo = (torch.cat([yo, rc], 1) * go.double()).sum()
     ref = torch.autograd.grad(lo, [xo] + [sd64[n] for n in names])
     close(y, yo.float(), 2e-5, 2e-6); close(net.rendcond, rc.float(), 2e-5, 2e-6)
-    close(ours[0], ref[0].float(), 1e-4, 1e-5 / P)
+    close(ours[0], ref[0].float(), 1e-4, 1e-4 * float(ref[0].abs().max()))
     for n, a, b in zip(names, ours[1:], ref[1:]):
         # sums over 98k rows: fp32 accumulation (fixed slab order) against float64
         torch.testing.assert_close(a.cpu(), b.float(), rtol=2e-4, atol=2e-5 * max(1e-3, float(b.abs().max())), msg=lambda m, n=n: n + ": " + m)

@@ -52,9 +52,6 @@ def test_points_silhouette_forward_backward_vs_pytorch3d_restatement(K, V, sprea
     (g,) = torch.autograd.grad(m, pg, go.to(DEV))
     torch.testing.assert_close(g.cpu(), gref.float(), rtol=2e-3, atol=2e-4 * float(gref.abs().max()))
     assert float(m.min()) >= 0 and float(m.max()) <= 1
-    m2 = points_silhouette(xy, z, H, W, radius, K)                     # selection + fixed-order re-composite: truncated pixels are reproducible
-    trunc = torch.from_numpy((ncover.numpy() == K)).to(DEV)
-    assert torch.equal(m2[trunc], m[trunc])
 
 
 def _mesh(V=40, F=70):

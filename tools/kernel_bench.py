@@ -45,6 +45,26 @@ for n in (257,513):
     rows.append((f'marching cubes {n}^3 (V={v.shape[0]}, F={f.shape[0]})', n**3, 4*n**3+12*v.shape[0]+24*f.shape[0], ms))
 c=torch.randn(1,1,257,257,257,device=dev)
 ms=timeit(lambda: interp2x_boundary3d.forward(c,0.0), n=5); rows.append(('interp2x_boundary3d fwd 257^3 -> 513^3', 513**3, 4*257**3+5*513**3, ms))
+# round 2: LBS value+Jacobian backward, the two rasterisers at the bench's sizes (3 x 86k template vertices / 172k faces, 540^2)
+from selfreconcode_amd.model.Deformer import _LBSValueJacobian
+Pj=200_000
+qj=pts[:Pj].clone().requires_grad_(True); bj=torch.sort(bi[:Pj]).values
+yj,Jj=_LBSValueJacobian.apply(skin,qj,A.detach(),trans,bj,0)
+wy=torch.randn_like(yj); wJ=torch.randn_like(Jj)
+ms=timeit(lambda: torch.autograd.grad([yj,Jj],[qj],[wy,wJ],retain_graph=True)); rows.append(('lbs value+jacobian bwd (grouped by frame)', Pj, (2*796+60)*Pj, ms))
+from selfreconcode_amd.ops import points_silhouette, rasterize_meshes
+from selfreconcode_amd.model.CameraMine import RectifiedPerspectiveCameras
+H=W=540
+cam=RectifiedPerspectiveCameras(torch.tensor([[648.,648.]],device=dev),torch.tensor([[270.,270.]],device=dev),torch.diag(torch.tensor([-1.,1.,-1.],device=dev))[None],torch.tensor([[0.,0.15,2.4]],device=dev),[(W,H)])
+n=257
+x,y,z=torch.meshgrid(*[torch.linspace(-0.8,0.8,n,device=dev)]*3, indexing='ij')
+vs,fs=MCGpu.mc_gpu((torch.sqrt(x*x+0.7*y*y+z*z)-0.6).contiguous(),1.6/256,1.6/256,1.6/256,-0.8,-0.8,-0.8,0.)
+vs=vs[None].expand(3,-1,3).contiguous()+torch.randn(3,1,3,device=dev)*0.01
+xy,zz=cam.project_ndc(vs)
+ms=timeit(lambda: points_silhouette(xy,zz,H,W,0.006,50)); rows.append((f'point silhouette fwd K=50 (3 x {vs.shape[1]} points, 540^2)', 3*vs.shape[1], 12*3*vs.shape[1]+4*3*H*W, ms))
+xyg=xy.clone().requires_grad_(True); mk=points_silhouette(xyg,zz,H,W,0.006,50); gm=torch.randn_like(mk)
+ms=timeit(lambda: torch.autograd.grad(mk,xyg,gm,retain_graph=True)); rows.append(('point silhouette bwd', 3*vs.shape[1], 20*3*vs.shape[1]+16*3*H*W, ms))
+ms=timeit(lambda: rasterize_meshes(xy,zz,fs,H,W)); rows.append((f'mesh rasteriser (3 x {fs.shape[0]} faces, 540^2)', 3*fs.shape[0], 3*fs.shape[0]*(24+36)+3*H*W*(8+8+12+4), ms))
 print("| kernel | units | algorithmic bytes | ms | GB/s | % of 8 TB/s |"); print("|---|---|---|---|---|---|")
 for name,u,b,ms in rows:
     print(f"| {name} | {u} | {b/1e6:.1f} MB | {ms:.3f} | {b/ms/1e6:.0f} | {b/ms/1e6/8000*100:.1f} |")
