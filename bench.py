@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--no-fine", action="store_true", help="skip the fine-stage record of the default single-GPU run")
     ap.add_argument("--refiner-stream", choices=["main", "side"], default="main", help="run the refiner after (main) or concurrently with (side) the template branch")
     ap.add_argument("--refiner-impl", choices=["device", "layerwise"], default="device", help="device-driven compacting refiner or the layer-by-layer host loop")
+    ap.add_argument("--no-sdf-throughput", action="store_true", help="skip the SDF-MLP Gsamples/s leg (PMC passes: keeps the launch population = the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true", help="skip the HIP-event pairs around the layer GEMMs (roofline leg) to see their cost")
     ap.add_argument("--shape-log", default=None, help="write the per-(M,N,K) GEMM launch table (events) to this JSON file")
@@ -171,14 +172,15 @@ def main():
     elapsed = main_rec.pop("elapsed")
 
     # secondary headline: SDF MLP forward throughput (no-grad, 393216 samples per call)
+    sdf_gs = 0.0
     with torch.no_grad():
-        x = (torch.rand(393216, 3, device=device) - 0.5) * 1.6
+        x = (torch.rand(393216 if not args.no_sdf_throughput else 0, 3, device=device) - 0.5) * 1.6
         for _ in range(2):
             net.sdf(x, 1.0)
         torch.cuda.synchronize(); s = time.perf_counter()
         for _ in range(5):
             net.sdf(x, 1.0)
-        torch.cuda.synchronize(); sdf_gs = 5 * x.shape[0] / (time.perf_counter() - s) / 1e9
+        torch.cuda.synchronize(); sdf_gs = 5 * x.shape[0] / (time.perf_counter() - s) / 1e9 if x.shape[0] else 0.0
     V = main_rec["template_vertices"]
     del net
     gc.collect(); torch.cuda.empty_cache()

@@ -304,8 +304,12 @@ __device__ __forceinline__ Box tri_box(const Tri& t, int H, int W) {
   const float xmin = fminf(t.x0, fminf(t.x1, t.x2)), xmax = fmaxf(t.x0, fmaxf(t.x1, t.x2));
   const float ymin = fminf(t.y0, fminf(t.y1, t.y2)), ymax = fmaxf(t.y0, fmaxf(t.y1, t.y2));
   Box b;
-  b.c0 = max(0, (int)floorf(((1.0f - xmax) * (float)W - 1.0f) * 0.5f) - 1); b.c1 = min(W - 1, (int)ceilf(((1.0f - xmin) * (float)W - 1.0f) * 0.5f) + 1);
-  b.r0 = max(0, (int)floorf(((1.0f - ymax) * (float)H - 1.0f) * 0.5f) - 1); b.r1 = min(H - 1, (int)ceilf(((1.0f - ymin) * (float)H - 1.0f) * 0.5f) + 1);
+  // centre of column c lies in [xmin, xmax]  <=>  c in [col(xmax), col(xmin)], col(x) = ((1 - x) W - 1) / 2; the 1e-3 pixel of slack
+  // covers the rounding of this inverse map (raster_pixel repeats the exact NDC test), and keeps the box tight: most faces of a
+  // remeshed template cover 0-2 pixel centres and must stay on the one-lane path
+  const float eps = 1e-3f;
+  b.c0 = max(0, (int)ceilf(((1.0f - xmax) * (float)W - 1.0f) * 0.5f - eps)); b.c1 = min(W - 1, (int)floorf(((1.0f - xmin) * (float)W - 1.0f) * 0.5f + eps));
+  b.r0 = max(0, (int)ceilf(((1.0f - ymax) * (float)H - 1.0f) * 0.5f - eps)); b.r1 = min(H - 1, (int)floorf(((1.0f - ymin) * (float)H - 1.0f) * 0.5f + eps));
   return b;
 }
 
@@ -321,7 +325,7 @@ __device__ __forceinline__ void raster_pixel(const Tri& t, int c, int r, int64_t
   if (key < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, key);   // most fragments lose: skip the RMW
 }
 
-constexpr int RASTER_SMALL = 48;   // pixel tests a single lane does itself; larger boxes go to the wave-per-face pass
+constexpr int RASTER_SMALL = 32;   // pixel tests a single lane does itself; larger boxes go to the wave-per-face pass
 
 __global__ __launch_bounds__(256) void rm_pass1(const float* __restrict__ xy, const float* __restrict__ z, const int64_t* __restrict__ faces,
                                                  int64_t nimg, int64_t V, int64_t F, int H, int W, unsigned long long* __restrict__ zbuf,
@@ -333,6 +337,7 @@ __global__ __launch_bounds__(256) void rm_pass1(const float* __restrict__ xy, co
     if (!load_tri(xy, z, faces, img, V, f, t)) continue;
     const Box b = tri_box(t, H, W);
     if (b.c1 < b.c0 || b.r1 < b.r0) continue;
+    if (!(fabsf(t.x0) < 8.f && fabsf(t.x1) < 8.f && fabsf(t.x2) < 8.f && fabsf(t.y0) < 8.f && fabsf(t.y1) < 8.f && fabsf(t.y2) < 8.f)) continue;   // NaN / wildly off-screen vertex
     if ((b.c1 - b.c0 + 1) * (b.r1 - b.r0 + 1) > RASTER_SMALL) {
       const unsigned long long slot = atomicAdd(big_count, 1ull);
       if ((int64_t)slot < big_cap) { big_list[slot] = i; continue; }

@@ -411,7 +411,8 @@ def deformer_value_jacobian(deformer, ps, defconds, batch_inds, ratio):
     q, Jq = translator_value_jacobian(tr, ps, d_cond, batch_inds, ratio)
     A = skin.posed_transforms(poses)
     y, Jl = _LBSValueJacobian.apply(skin, q, A, trans, batch_inds, 0)
-    return y, torch.bmm(Jl, Jq)
+    from ..utils.utils import small_matmul
+    return y, small_matmul(Jl, Jq)
 
 
 def is_fused_composite(deformer):

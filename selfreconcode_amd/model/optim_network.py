@@ -478,12 +478,12 @@ class OptimNetwork(nn.Module):
             if getattr(self, "_flip", None) is None or self._flip.device != device:
                 self._flip = torch.tensor([[-1., 0., 0.], [0., 1., 0.], [0., 0., -1.]], device=device)      # cached: an H2D copy is a sync point
             flip = self._flip
-            gtnormals = ((cameras.R[0] @ flip) @ gtnormals.view(-1, 3, 1)).view(-1, 3)
+            gtnormals = gtnormals.view(-1, 3) @ (cameras.R[0] @ flip).t()
             gtnorms = gtnormals.norm(dim=1, keepdim=True)
             valid_mask = (gtnorms > 0.0001)[..., 0]
             gtnormals = torch.where(valid_mask[:, None], gtnormals / gtnorms.clamp(min=1e-12), gtnormals)
             grad_d_p = jac['J']
-            gtnormals = (grad_d_p.transpose(-2, -1) @ gtnormals.view(-1, 3, 1)).view(-1, 3)
+            gtnormals = U.small_matvec(grad_d_p.transpose(-2, -1), gtnormals.view(-1, 3))
             normal_loss = (gtnormals - nx).norm(2, dim=1) * weights
             # scatter-mean over the valid rows without materialising the subset (no host sync): masked sums / masked counts
             zero = torch.zeros((), dtype=normal_loss.dtype, device=device)
@@ -557,22 +557,22 @@ class OptimNetwork(nn.Module):
         grad_d_p = grad_d_p.detach()                                   # graphs of f and d are kept: they are back-propagated below
         opt_defconds = [t for t in (d_cond, poses, trans) if t.requires_grad]
         v_cross = cross_matrix(v)
-        b = torch.cat([grad_f_p.view(-1, 1, 3), v_cross.matmul(grad_d_p)], dim=1)
-        btb = b.permute(0, 2, 1).matmul(b)
+        b = torch.cat([grad_f_p.view(-1, 1, 3), U.small_matmul(v_cross, grad_d_p)], dim=1)
+        btb = U.small_matmul(b.permute(0, 2, 1), b)
         btb_inv, check = Fast3x3Minv(btb.contiguous())
         self.info['invInfo'] = (check.numel(), check.sum())
-        rhs_1 = grad_l_p.view(-1, 1, 3).matmul(btb_inv.matmul(b.permute(0, 2, 1)))        # [P,1,4]
+        rhs_1 = U.small_matmul(grad_l_p.view(-1, 1, 3), U.small_matmul(btb_inv, b.permute(0, 2, 1)))        # [P,1,4]
         # The reference builds a surrogate loss sum(param * grad) from three autograd.grad calls and back-propagates it
         # (network.py:773-814); that adds `grad` to every parameter's .grad, which is exactly one backward of
         # (f, d) with the cotangents (-rhs_f, temp).
         # (The reference evaluates f and d a second time at p.detach() for this; the weights have not moved since the evaluations
         # above, so those graphs are reused and the backward is restricted to the learnable leaves -- p itself gets no gradient.)
         f2, d2 = f, d
-        temp = (rhs_1[:, :, -3:].matmul(-v_cross)).view(-1, 3)
+        temp = U.small_matmul(rhs_1[:, :, -3:], -v_cross).view(-1, 3)
         outs, cots = [f2, d2], [(-rhs_1[:, :, 0]).reshape(f2.shape).detach(), temp.detach()]
         if v_live.requires_grad:                      # d/dv of [v]x (d - c): network.py:798-809
             dc_cross = cross_matrix(d2.detach() - c_live.detach().view(1, 3))
-            outs.append(v_live); cots.append(rhs_1[:, :, -3:].matmul(dc_cross).view(-1, 3).detach())
+            outs.append(v_live); cots.append(U.small_matmul(rhs_1[:, :, -3:], dc_cross).view(-1, 3).detach())
         if c_live.requires_grad:                      # network.py:811-813
             outs.append(c_live); cots.append((-temp.sum(0)).detach())
         lw = getattr(self.dataset, 'learnable_weights', None)

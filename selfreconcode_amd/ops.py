@@ -23,7 +23,7 @@ class SingularValues3x3(Function):
     @staticmethod
     def backward(ctx, gS):
         U, V = ctx.saved_tensors
-        return (U * gS.unsqueeze(1)) @ V.transpose(1, 2)
+        return ((U * gS.unsqueeze(1)).unsqueeze(-1) * V.transpose(1, 2).unsqueeze(-3)).sum(-2)      # 3x3 products: see utils.small_matmul
 
 
 def singular_values_3x3(J):

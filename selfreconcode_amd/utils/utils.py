@@ -23,6 +23,18 @@ class FastDiff3x3MinvFunction(Function):
         return Fast3x3Minv_backward(grad_input.contiguous(), invs), None
 
 
+def small_matmul(a, b):
+    """Batched product of tiny matrices ([..., m, k] x [..., k, n], m, k, n <= 4) as one broadcast multiply and one reduction:
+    the vendor batched GEMM (what `@` dispatches to) takes 40-130 us for a few thousand 3x3 products, two elementwise launches
+    take ~10.  Same values up to the order of the k-sum; differentiable to any order."""
+    return (a.unsqueeze(-1) * b.unsqueeze(-3)).sum(-2)
+
+
+def small_matvec(a, v):
+    """[..., m, k] x [..., k] -> [..., m] (see small_matmul)."""
+    return (a * v.unsqueeze(-2)).sum(-1)
+
+
 def annealing_weights(multires, ratio):
     """utils/utils.py:40-46."""
     alpha = ratio * multires
@@ -141,11 +153,11 @@ def compute_deformed_normals(sdf, deformer, ps, defconds, batch_inds, ratio, pha
     else:
         ds, grad_d_p = deformed_points_and_jacobian(deformer, ps, defconds, batch_inds, ratio, check)
     grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
-    nx = grad_d_p_inv.transpose(-2, -1).matmul(onx.view(-1, 3, 1)).view(-1, 3)
+    nx = small_matvec(grad_d_p_inv.transpose(-2, -1), onx.view(-1, 3))
     # singular Jacobians fall back to J n (reference :145-150).  The reference tests the mask on the host and prints a warning
     # (one sync per call); here the selection is a device-side where() and the count is left in SINGULAR_COUNT for whoever asks.
     SINGULAR_COUNT['normals'] = (~inv_mask).sum()
-    nx = torch.where(inv_mask[:, None], nx, grad_d_p.matmul(onx.unsqueeze(-1)).view(-1, 3))
+    nx = torch.where(inv_mask[:, None], nx, small_matvec(grad_d_p, onx.view(-1, 3)))
     nx = nx / nx.norm(dim=1, keepdim=True)
     return nx, ds
 
@@ -161,7 +173,7 @@ def compute_cardinal_rays(deformer, ps, rays, defconds, batch_inds, ratio, phase
         if cache is not None:
             cache['ds'], cache['J'] = ds, grad_d_p
     grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
-    crays = grad_d_p_inv.matmul(rays.view(-1, 3, 1)).view(-1, 3)
+    crays = small_matvec(grad_d_p_inv, rays.view(-1, 3))
     SINGULAR_COUNT['rays'] = (~inv_mask).sum()          # (reference :162-167: host test + print; see compute_deformed_normals)
     crays = torch.where(inv_mask[:, None], crays, rays.detach())
     crays = crays / crays.norm(dim=1, keepdim=True)

@@ -19,7 +19,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $PROF > $O
 find $OUT/stats -name "*kernel_trace.csv" -delete
 # 3. HBM traffic of the layer GEMMs: FETCH_SIZE and WRITE_SIZE in separate passes, + the calibration launches
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python $R/bench.py --steps 4 --warmup 2 --settle 0 --settle-low 4 --noise-observations --no-fine --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python $R/bench.py --steps 6 --warmup 0 --settle 0 --settle-low 0 --noise-observations --no-fine --no-cpu-baseline --no-sdf-throughput --shape-log $OUT/pmc_shapes_$C.json > $OUT/pmc_$C.log 2>&1
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/cal_$C -- python $R/tools/pmc_calibrate.py > $OUT/cal_$C.log 2>&1
   python - "$OUT" "$C" <<'PY'
 import csv, glob, sys, json, collections
@@ -30,7 +30,10 @@ def collect(d, by_grid=False):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] != c: continue
             n = r['Kernel_Name']
-            key = 'gemm_nt_kernel' if 'gemm_nt_kernel' in n else 'gemm_tn_kernel' if 'gemm_tn_kernel' in n else 'mlp_chain_kernel' if 'mlp_chain_kernel' in n else None
+            if 'gemm_nt_kernel' in n:      # per tile configuration: <2,2,*,*> are the wide-output launches the shape log records
+                key = 'gemm_nt_kernel' + n[n.index('<'):n.index('>') + 1].replace(' ', '')
+            else:
+                key = 'gemm_tn_kernel' if 'gemm_tn_kernel' in n else 'mlp_layer_pair_kernel' if 'mlp_layer_pair_kernel' in n else None
             if not key: continue
             if by_grid: key = key + ' grid ' + r['Grid_Size']
             agg[key][0] += 1; agg[key][1] += float(r['Counter_Value'])
