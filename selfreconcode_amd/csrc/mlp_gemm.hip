@@ -724,6 +724,8 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
     // measured 31.5 / 39.9 / 45 us.)
     static const int forced = getenv("SR_NT_CFG") ? atoi(getenv("SR_NT_CFG")) : 0;   // tuning switch
     int pick = forced;
+    static const int smallk = getenv("SR_NT_SMALLK") ? atoi(getenv("SR_NT_SMALLK")) : 0;   // tuning switch: tile configuration for K <= 64
+    if (!pick && smallk && g.K <= 64) pick = smallk;
     if (!pick) {
       const double c[3] = {cost(64, 64, 0.92), cost(64, 128, 0.94), cost(128, 128, 1.0)};
       pick = 1;

@@ -215,18 +215,19 @@ def test_deferred_gradients_equal_plain_autograd_over_a_full_iteration():
 
 
 def test_camera_parameters_receive_gradients_when_learnable():
-    """opt_camera (config.conf:12-17): focal length / principal point / T learnable -> both the loss graph and
+    """opt_camera (config.conf:12-17): focal length / principal point / T / quaternion learnable -> both the loss graph and
     propagateTmpPsGrad's v- and c-terms (network.py:798-813) must reach them."""
     from selfreconcode_amd.synthetic import build_synthetic_scene
     net, ds, conf = build_synthetic_scene(device=DEV, frame_num=40, H=128, W=128, resolutions=[(15, 21, 9), (29, 41, 17), (57, 81, 33)],
                                           lbs_volume_shape=(17, 57, 33))
-    for k in ('focal_length', 'princeple_points', 'world2cam_coord_trans'):
-        ds.camera_params[k].requires_grad_(True)
+    keys = ('focal_length', 'princeple_points', 'world2cam_coord_trans', 'cam2world_coord_quat')
+    for k in keys:                                   # incl. the quaternion: its graph (normalise -> R) saves tensors, so the silhouette
+        ds.camera_params[k].requires_grad_(True)     # projection back-propagated INSIDE forward() must not share it with the rays
     fids = torch.tensor([3, 11, 20], device=DEV)
     r = {'sdfRatio': 1., 'deformerRatio': 0.5, 'renderRatio': 1.}
     loss = net(ds.batch(fids), 512, r, fids)
     loss.backward()
-    g0 = {k: ds.camera_params[k].grad.clone() for k in ('focal_length', 'princeple_points', 'world2cam_coord_trans')}
+    g0 = {k: ds.camera_params[k].grad.clone() for k in keys}
     net.propagateTmpPsGrad(fids, r)
     for k, g in g0.items():
         g1 = ds.camera_params[k].grad
