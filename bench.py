@@ -120,7 +120,7 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
         step()
     net.remesh_events = []
     mlp_engine.PROFILE.reset(enabled=gemm_events, reserve=800 * steps if gemm_events else 0)
-    net.refiner_events = [] if gemm_events else None
+    net.refiner_events = []
     el, rays, cf = timed(steps)
     prof = mlp_engine.PROFILE.summary()
     shapes = mlp_engine.PROFILE.by_shape() if gemm_events else None
@@ -234,7 +234,9 @@ def main():
             with open(pmc) as fh:
                 t = json.load(fh)
             out["roofline"]["traffic"] = round(t["traffic_bytes_per_launch"])
-            out["roofline"]["traffic_note"] = f"HBM bytes per launch, mean over all launches of the kernel family (separate rocprofv3 --pmc passes, profiles/{name})"
+            out["roofline"]["traffic_note"] = (f"HBM bytes per launch of the wide-output layer GEMMs, calibrated FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc "
+                                               f"passes (profiles/{name}; algorithmic bytes of the same launches: "
+                                               f"{round(t.get('gemm_nt_wide', {}).get('algorithmic_bytes_per_launch', 0))})")
             break
     if shapes is not None and args.shape_log:
         with open(args.shape_log, "w") as fh:

@@ -85,7 +85,7 @@ def test_chain_equals_layerwise_launches_on_a_device_row_count():
         _lib.call("sr_mlp_chain", ctypes.byref(fwd), _lib.stream_of(x)); torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("P,times", [(5000, 10), (777, 3), (64, 10)])
+@pytest.mark.parametrize("P,times", [(5000, 10), (777, 3), (64, 10), (130, 2)])
 def test_device_driven_refiner_equals_the_layerwise_loop(P, times):
     from selfreconcode_amd.utils import FindSurfacePs as F
     sdf, comp = _nets()
@@ -119,13 +119,39 @@ def test_device_driven_refiner_equals_the_layerwise_loop(P, times):
     # Same arithmetic per ray, but a row's tile is an interior or an edge tile depending on where the compaction put it, and the
     # two epilogue instantiations contract their multiply-adds differently (1 ulp); the residual iteration amplifies that for
     # the rays that zigzag towards a threshold.  So: flags equal up to threshold flips, nearly all points equal to 5e-6, none far.
-    assert (oa == ob).float().mean() > 0.985
+    assert int((oa != ob).sum()) <= max(3, int(0.015 * P))
     same = oa == ob
     dev_ = (pb[same] - pa[same]).abs().max(dim=1).values
-    assert (dev_ < 5e-6).float().mean() > 0.97 and float(dev_.max()) < 5e-3, ((dev_ < 5e-6).float().mean(), dev_.max())
+    assert int((dev_ >= 5e-6).sum()) <= max(4, int(0.03 * P)) and float(dev_.max()) < 5e-3, (int((dev_ >= 5e-6).sum()), dev_.max())
     # the queue really shrinks: live counts per phase (device memory, read back here only)
     ws = [w for (dev, cap), w in F._WORKSPACES.items() if cap == (P + 1023) // 1024 * 1024][0]
     live = ws.live[:times + 2].cpu().tolist()
     assert live[0] == P and all(a >= b for a, b in zip(live, live[1:]))
     assert 0.15 * P < P - live[1] < 0.6 * P                                   # the on-surface quarter is retired by the initial test
-    assert live[times + 1] < 0.5 * P and float(ob.float().mean()) > 0.5, (live, float(ob.float().mean()))   # and most of the rest along the way
+    if times >= 10:
+        assert live[times + 1] < 0.5 * P and float(ob.float().mean()) > 0.5, (live, float(ob.float().mean()))   # and most of the rest along the way
+
+
+def test_refiner_edge_cases():
+    """No rays, one ray, zero steps: the fixed launch sequence must cope (grids sized from the ray count, queue compaction on
+    partial waves)."""
+    from selfreconcode_amd.utils import FindSurfacePs as F
+    sdf, comp = _nets()
+    N = 3
+    defconds = [fx.det_tensor((N, 128), 3, 0.1).to(DEV), [fx.det_tensor((N, 24, 3), 1, 0.1).to(DEV), fx.det_tensor((N, 3), 2, 0.05).to(DEV)]]
+    cam = torch.tensor([0., 0.15, 2.4], device=DEV)
+    ps, ok = F.OptimizeSurfacePs(cam, torch.zeros(0, 3, device=DEV), torch.zeros(0, 3, device=DEV), torch.zeros(0, dtype=torch.long, device=DEV), sdf, RATIO,
+                                 comp, defconds, times=10)
+    assert ps.shape == (0, 3) and ok.shape == (0,)
+    p0 = torch.tensor([[0.0, 0.0, 0.6]], device=DEV)
+    rays = torch.nn.functional.normalize(p0 - cam, dim=1)
+    for times in (0, 10):
+        outs = []
+        for flag in (False, True):
+            F.DEVICE_DRIVEN = flag
+            ps, ok = F.OptimizeSurfacePs(cam, rays, p0.clone(), torch.zeros(1, dtype=torch.long, device=DEV), sdf, RATIO, comp, defconds,
+                                         dthreshold=5e-5, athreshold=0.3, times=times)
+            assert ps.shape == (1, 3) and torch.isfinite(ps).all()
+            outs.append((ps.cpu(), ok.cpu()))
+        F.DEVICE_DRIVEN = True
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.allclose(outs[0][0], outs[1][0], atol=5e-6)
