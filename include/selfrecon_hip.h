@@ -311,6 +311,18 @@ int sr_mc_emit(const float* sdf, int32_t nx, int32_t ny, int32_t nz, float iso, 
  */
 int sr_svd3x3(const float* A, int64_t n, float* U, float* S, float* V, void* stream);
 
+/* Effective weights of up to SR_PACK_MAX_LAYERS linear layers in one launch (weight_norm dim 0 as model/network.py:65-66 and
+ * model/RenderNet.py:46-47: W = g v/|v|; g NULL = plain layer): W [N, ldw] zero padded, WT [K, ldwt] = W^T zero padded,
+ * norms [N] = |v_n|.  _unpack is the backward: dW [N, lddw] -> gv [N, K] (and gg [N] for weight-normed layers), i.e.
+ * aten::_weight_norm_interface_backward; accumulate != 0 adds to gv / gg. */
+#define SR_PACK_MAX_LAYERS 16
+typedef struct { const float* v; const float* g; float* W; float* WT; float* norms; int32_t N, K; int64_t ldw, ldwt; } sr_pack_layer;
+typedef struct { int32_t nlayers; sr_pack_layer layer[SR_PACK_MAX_LAYERS]; } sr_pack_table;
+typedef struct { const float* dW; int64_t lddw; const float* v; const float* g; const float* norms; float* gv; float* gg; int32_t N, K, accumulate; } sr_unpack_layer;
+typedef struct { int32_t nlayers; sr_unpack_layer layer[SR_PACK_MAX_LAYERS]; } sr_unpack_table;
+int sr_pack_weights(const sr_pack_table* host_table, void* stream);
+int sr_unpack_grads(const sr_unpack_table* host_table, void* stream);
+
 /* ---------------------------------------------------------------- interp2x_boundary3d (K10/K11)
  * Replaces MCAcc/cuda/interp2x_boundary3d.cpp:forward/backward -> interp2x_boundary3d_kernel.cu:11-151, 155-239
  * (compiled but never enabled in the reference: every Seg3dLossless is built with use_cuda_impl=False).

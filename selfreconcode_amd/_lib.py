@@ -69,6 +69,26 @@ class SrRefineArgs(ctypes.Structure):
                 ("a0dbar", _vp), ("ld_a0dbar", _i64), ("p_out", _vp), ("conv_out", _vp)]
 
 
+SR_PACK_MAX_LAYERS = 16
+
+
+class SrPackLayer(ctypes.Structure):
+    _fields_ = [("v", _vp), ("g", _vp), ("W", _vp), ("WT", _vp), ("norms", _vp), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("ldw", _i64), ("ldwt", _i64)]
+
+
+class SrPackTable(ctypes.Structure):
+    _fields_ = [("nlayers", ctypes.c_int32), ("layer", SrPackLayer * SR_PACK_MAX_LAYERS)]
+
+
+class SrUnpackLayer(ctypes.Structure):
+    _fields_ = [("dW", _vp), ("lddw", _i64), ("v", _vp), ("g", _vp), ("norms", _vp), ("gv", _vp), ("gg", _vp), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("accumulate", ctypes.c_int32)]
+
+
+class SrUnpackTable(ctypes.Structure):
+    _fields_ = [("nlayers", ctypes.c_int32), ("layer", SrUnpackLayer * SR_PACK_MAX_LAYERS)]
+
+
 class SrError(RuntimeError):
     pass
 
@@ -122,6 +142,8 @@ SIGNATURES = {
     "sr_mc_workspace_bytes": [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32],
     "sr_mc_count": [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp],
     "sr_mc_emit": [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp] + [ctypes.c_float] * 6 + [_vp, _vp, _vp],
+    "sr_pack_weights": [_vp, _vp],
+    "sr_unpack_grads": [_vp, _vp],
     "sr_svd3x3": [_vp, _i64, _vp, _vp, _vp, _vp],
     "sr_points_silhouette_workspace_bytes": [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float],
     "sr_points_silhouette_fwd": [_vp, _vp, _i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_int32, _vp, _vp, _vp],

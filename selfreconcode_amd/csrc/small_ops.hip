@@ -74,3 +74,91 @@ int sr_svd3x3(const float* A, int64_t n, float* U, float* S, float* V, void* str
   return sr_launch_status();
 }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Effective-weight packing and its backward for ALL layers of a network in one launch each.
+// pack : W[n, :] = g[n] v[n, :] / |v[n, :]| (weight_norm dim 0, model/network.py:65-66; plain copy when g is null), padded to the
+//        row pitch; WT = W^T padded (feeds the backward-data GEMM); norms[n] = |v[n, :]|.  The reference recomputes the weight norm
+//        in a forward pre-hook at every module call; torch ops here took ~5 launches per layer per optimizer step.
+// unpack (backward): gv[n, :] = (g/|v|) (dW[n, :] - v[n, :] <dW[n, :], v[n, :]> / |v|^2),  gg[n] = <dW[n, :], v[n, :]> / |v|
+//        (aten::_weight_norm_interface_backward), or gw = dW[:, :K] for a plain layer; optionally added to existing gradients.
+// One wave per weight row.
+namespace {
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(sr_pack_table t) {
+  const sr_pack_layer L = t.layer[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = gridDim.x * (blockDim.x >> 6);
+  for (int n = wave; n < L.ldwt; n += nwaves) {          // rows [N, ldwt) only zero the pad columns of WT
+    if (n < L.N) {
+      const float* v = L.v + (int64_t)n * L.K;
+      float scale = 1.f;
+      if (L.g) {
+        float ss = 0.f;
+        for (int k = lane; k < L.K; k += 64) ss += v[k] * v[k];
+        const float nrm = sqrtf(wave_sum64(ss));
+        if (lane == 0) L.norms[n] = nrm;
+        scale = L.g[n] / nrm;
+      }
+      for (int k = lane; k < L.ldw; k += 64) {
+        const float w = k < L.K ? v[k] * scale : 0.f;
+        L.W[(int64_t)n * L.ldw + k] = w;
+        if (k < L.K) L.WT[(int64_t)k * L.ldwt + n] = w;
+      }
+    } else {
+      for (int k = lane; k < L.K; k += 64) L.WT[(int64_t)k * L.ldwt + n] = 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void unpack_grads_kernel(sr_unpack_table t) {
+  const sr_unpack_layer L = t.layer[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = gridDim.x * (blockDim.x >> 6);
+  for (int n = wave; n < L.N; n += nwaves) {
+    const float* d = L.dW + (int64_t)n * L.lddw;
+    float* gv = L.gv + (int64_t)n * L.K;
+    if (L.g) {
+      const float* v = L.v + (int64_t)n * L.K;
+      float dot = 0.f;
+      for (int k = lane; k < L.K; k += 64) dot += d[k] * v[k];
+      dot = wave_sum64(dot);
+      const float nrm = L.norms[n], inv = 1.f / nrm;
+      const float a = L.g[n] * inv, b = dot * inv * inv;
+      for (int k = lane; k < L.K; k += 64) {
+        const float val = a * (d[k] - v[k] * b);
+        gv[k] = L.accumulate ? gv[k] + val : val;
+      }
+      if (lane == 0) L.gg[n] = (L.accumulate ? L.gg[n] : 0.f) + dot * inv;
+    } else {
+      for (int k = lane; k < L.K; k += 64) gv[k] = L.accumulate ? gv[k] + d[k] : d[k];
+    }
+  }
+}
+}  // namespace
+
+extern "C" {
+int sr_pack_weights(const sr_pack_table* t, void* stream) {
+  if (!t || t->nlayers < 1 || t->nlayers > SR_PACK_MAX_LAYERS) return SR_EINVAL;
+  for (int l = 0; l < t->nlayers; ++l) {
+    const sr_pack_layer& L = t->layer[l];
+    if (!L.v || !L.W || !L.WT || L.N <= 0 || L.K <= 0 || L.ldw < L.K || L.ldwt < L.N || (L.g && !L.norms)) return SR_EINVAL;
+  }
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(32, t->nlayers), dim3(256), 0, (hipStream_t)stream, *t);
+  return sr_launch_status();
+}
+int sr_unpack_grads(const sr_unpack_table* t, void* stream) {
+  if (!t || t->nlayers < 1 || t->nlayers > SR_PACK_MAX_LAYERS) return SR_EINVAL;
+  for (int l = 0; l < t->nlayers; ++l) {
+    const sr_unpack_layer& L = t->layer[l];
+    if (!L.dW || !L.gv || L.N <= 0 || L.K <= 0 || L.lddw < L.K || (L.g && (!L.v || !L.norms || !L.gg))) return SR_EINVAL;
+  }
+  hipLaunchKernelGGL(unpack_grads_kernel, dim3(32, t->nlayers), dim3(256), 0, (hipStream_t)stream, *t);
+  return sr_launch_status();
+}
+}

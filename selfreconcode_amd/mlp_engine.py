@@ -438,11 +438,63 @@ class PackPlain(torch.autograd.Function):
         return None if gW is None else gW[:, :ctx.K]
 
 
+FUSED_PACK = True       # refresh all stale packs of a network with ONE launch (sr_pack_weights) instead of ~5 torch launches per layer
+
+
+def refresh_packs(lins):
+    """Brings the pack entries of `lins` (the nn.Linear layers of one network) up to date with their parameters: entries that exist
+    and are stale (the optimizer stepped) are re-filled IN PLACE by one launch; entries that do not exist yet are left to the
+    per-layer torch path of pack_linear (first call only).  In-place refresh keeps every pointer (W, WT, gradient buffers)
+    stable across optimizer steps.  (A graph built on the old values must be back-propagated before the optimizer step that
+    precedes this refresh -- as every training loop does; the kernel writes the buffers behind torch's version counters.)"""
+    if not FUSED_PACK or not lins:
+        return
+    first = lins[0].weight_v if hasattr(lins[0], "weight_g") else lins[0].weight
+    if not first.is_cuda:
+        return
+    stale = []
+    for lin in lins:
+        wn = hasattr(lin, "weight_g")
+        v, g = (lin.weight_v, lin.weight_g) if wn else (lin.weight, None)
+        e = _PACK_CACHE.get(id(v))
+        if e is None:
+            continue
+        sig = _sig(v, g) if wn else _sig(v)
+        if e["sig"] != sig:
+            if e.get("dirty"):
+                raise RuntimeError("mlp_engine: parameters changed while deferred gradients were pending; call flush_param_grads() "
+                                   "before the optimizer step")
+            if e["W"].shape != (v.shape[0], pad4(v.shape[1])):
+                continue                                   # shape changed: let pack_linear rebuild it
+            stale.append((e, v, g, sig))
+    for i in range(0, len(stale), _lib.SR_PACK_MAX_LAYERS):
+        chunk = stale[i:i + _lib.SR_PACK_MAX_LAYERS]
+        t = _lib.SrPackTable()
+        t.nlayers = len(chunk)
+        for j, (e, v, g, sig) in enumerate(chunk):
+            L = t.layer[j]
+            vv = v.detach()
+            if not vv.is_contiguous():
+                vv = vv.contiguous()
+            L.v, L.g = _lib.ptr(vv), (0 if g is None else _lib.ptr(g.detach().contiguous()))
+            L.W, L.WT, L.norms = _lib.ptr(e["W"]), _lib.ptr(e["WT"]), (0 if g is None else _lib.ptr(e["norms"]))
+            L.N, L.K, L.ldw, L.ldwt = v.shape[0], v.shape[1], e["W"].stride(0), e["WT"].stride(0)
+        with torch.cuda.device(chunk[0][1].device), torch.no_grad():
+            _lib.call("sr_pack_weights", ctypes.byref(t), _lib.stream_of(chunk[0][1]))
+        for e, v, g, sig in chunk:
+            e["sig"] = sig
+
+
 def pack_linear(lin):
     """Padded effective weight of an nn.Linear, weight-normed (network.py:65-66) or plain."""
     if hasattr(lin, "weight_g"):
-        return PackWeightNorm.apply(lin.weight_v, lin.weight_g)
-    return PackPlain.apply(lin.weight)
+        W = PackWeightNorm.apply(lin.weight_v, lin.weight_g)
+    else:
+        W = PackPlain.apply(lin.weight)
+    e = _ENTRY_BY_PTR.get(W.data_ptr())
+    if e is not None:
+        e["bias_param"] = lin.bias
+    return W
 
 
 def transposed_of(W, K):
@@ -472,45 +524,83 @@ def _deferred_sink(W, b):
     """-> (dW buffer, db buffer, accumulate) or None.  Both buffers are private to the pack entry; the first weight-gradient GEMM
     after a flush OVERWRITES them (no zero fill), later ones add."""
     e = _ENTRY_BY_PTR.get(W.data_ptr())
-    if e is None or b is None or not b.requires_grad or not b.is_leaf or W.shape[0] != e["W"].shape[0]:
+    if e is None or b is None or not b.requires_grad or W.shape[0] > e["W"].shape[0] or W.stride(0) != e["W"].stride(0):
         return None
+    n, full = W.shape[0], W.shape[0] == e["W"].shape[0]
+    if full:
+        if not b.is_leaf:
+            return None
+    else:
+        # the leading rows of a layer (the sdf-only evaluation uses row 0 of the last SDF layer, with bias[:1]): same buffers, first
+        # rows.  `b` must then be the head of the layer's own bias parameter (registered by pack_linear).
+        base = e.get("bias_param")
+        if base is None or not base.is_leaf or not base.requires_grad or b.data_ptr() != base.data_ptr():
+            return None
+        b = base
     if e.get("dW") is None:
         e["dW"] = torch.empty_like(e["W"])
         e["db"] = torch.empty((e["W"].shape[0],), dtype=torch.float32, device=e["W"].device)
         e["fresh"] = True
+    if e["fresh"] and not full:                 # a partial first use: the rows it does not touch must read as zero at the flush
+        e["dW"].zero_(); e["db"].zero_()
+        e["fresh"] = False
     accumulate = not e["fresh"]
     e["fresh"] = False
     e["dirty"] = True
     e["bias"] = b
-    return e["dW"], e["db"], accumulate
+    return e["dW"][:n], e["db"][:n], accumulate
 
 
 def flush_param_grads(only=None):
-    """`only`: ids of parameter tensors (weight_v / weight) whose layers are flushed now; the rest stays pending."""
-    for e in list(_PACK_CACHE.values()):
-        if not e.get("dirty"):
-            continue
-        if only is not None and id(e["src"][0]) not in only:
-            continue
-        dW = e["dW"]
-        src = e["src"]
-        if len(src) == 2:                                  # weight-normed: (v, g)
-            v, g = src
-            gv, gg = torch.ops.aten._weight_norm_interface_backward(dW[:, :v.shape[1]].contiguous(), v.detach(), g.detach(), e["norms"], 0)
-            v.grad = gv if v.grad is None else v.grad.add_(gv)
-            g.grad = gg if g.grad is None else g.grad.add_(gg)
-        else:
-            w = src[0]
-            gw = dW[:, :w.shape[1]]
-            w.grad = gw.clone() if w.grad is None else w.grad.add_(gw)
-        b = e["bias"]
-        if b.grad is None:                                 # hand the buffer over instead of copying it; a new one is made on demand
-            b.grad = e["db"]
-            e["db"] = torch.empty_like(e["db"])
-        else:
-            b.grad.add_(e["db"])
-        e["fresh"] = True                                  # the next GEMM overwrites the buffers
-        e["dirty"] = False
+    """`only`: ids of parameter tensors (weight_v / weight) whose layers are flushed now; the rest stays pending.
+    All pending layers are turned into parameter gradients by ONE launch (sr_unpack_grads: weight-norm backward / plain copy)."""
+    todo = [e for e in _PACK_CACHE.values() if e.get("dirty") and (only is None or id(e["src"][0]) in only)]
+    if not todo:
+        return
+    for i in range(0, len(todo), _lib.SR_PACK_MAX_LAYERS):
+        chunk = todo[i:i + _lib.SR_PACK_MAX_LAYERS]
+        t = _lib.SrUnpackTable()
+        t.nlayers = len(chunk)
+        outs = []
+        for j, e in enumerate(chunk):
+            L = t.layer[j]
+            src = e["src"]
+            v = src[0]
+            g = src[1] if len(src) == 2 else None
+            acc = v.grad is not None and (g is None or g.grad is not None)
+            gv = v.grad if acc else torch.empty_like(v, memory_format=torch.contiguous_format)
+            gg = None
+            if g is not None:
+                gg = g.grad if acc else torch.empty_like(g, memory_format=torch.contiguous_format)
+            if acc and (not gv.is_contiguous() or (gg is not None and not gg.is_contiguous())):
+                acc = False                                  # (never the case for gradients made here) fall back to fresh tensors + add
+                gv = torch.empty_like(v, memory_format=torch.contiguous_format)
+                gg = None if g is None else torch.empty_like(g, memory_format=torch.contiguous_format)
+            vd = v.detach()
+            if not vd.is_contiguous():
+                vd = vd.contiguous()
+            L.dW, L.lddw = _lib.ptr(e["dW"]), e["dW"].stride(0)
+            L.v, L.g, L.norms = _lib.ptr(vd), (0 if g is None else _lib.ptr(g.detach().contiguous())), (0 if g is None else _lib.ptr(e["norms"]))
+            L.gv, L.gg, L.N, L.K, L.accumulate = _lib.ptr(gv), _lib.ptr(gg), v.shape[0], v.shape[1], 1 if acc else 0
+            outs.append((e, v, g, gv, gg, acc, vd))
+        dev = chunk[0]["W"].device
+        with torch.cuda.device(dev), torch.no_grad():
+            _lib.call("sr_unpack_grads", ctypes.byref(t), torch.cuda.current_stream(dev).cuda_stream)
+        for e, v, g, gv, gg, acc, _ in outs:
+            if acc:
+                pass                                         # added in place
+            else:
+                v.grad = gv if v.grad is None else v.grad.add_(gv)
+                if g is not None:
+                    g.grad = gg if g.grad is None else g.grad.add_(gg)
+            b = e["bias"]
+            if b.grad is None:                                 # hand the buffer over instead of copying it; a new one is made on demand
+                b.grad = e["db"]
+                e["db"] = torch.empty_like(e["db"])
+            else:
+                b.grad.add_(e["db"])
+            e["fresh"] = True                                  # the next GEMM overwrites the buffers
+            e["dirty"] = False
 
 
 def mlp_apply(spec, A0, Ws, bs):

@@ -9,6 +9,9 @@ from ..mlp_engine import MLPSpec, mlp_apply, pad_cols, pad4, pack_linear
 from ..utils.utils import resolve_band_weights
 
 
+HOIST_FRAME_CODE = __import__('os').environ.get('SR_HOIST_FRAME_CODE', '1') != '0'     # frame-major batches: per-frame code product out of the deformer's first-layer GEMM (MLPTranslator.hoisted_first_layer)
+
+
 class CompositeDeformer(nn.Module):
     def __init__(self, deformers):
         super().__init__()
@@ -47,6 +50,8 @@ class MLPTranslator(nn.Module):
         self.offset = None
 
     def packed_weights(self):
+        from ..mlp_engine import refresh_packs
+        refresh_packs([getattr(self, "lin" + str(l)) for l in range(len(self.spec.layers))])
         Ws, bs = [], []
         for l, L in enumerate(self.spec.layers):
             lin = getattr(self, "lin" + str(l))
@@ -54,9 +59,32 @@ class MLPTranslator(nn.Module):
             bs.append(lin.bias)
         return Ws, bs
 
+    def hoisted_first_layer(self, conds):
+        """The per-frame code enters the first layer only through W0[:, PE:] code_f -- a constant per frame.  For batches laid out
+        frame by frame ([N, V, 3]) that product is taken out of the per-point GEMM: the layer becomes [512 x 39] on PE(p) with a
+        per-frame bias B_f = W0[:, 39:] code_f + b0 (-15 % of the deformer's FLOPs, K = 167 -> 39 in the first-layer
+        forward, backward-data and weight-gradient GEMMs).  Plain torch ops: autograd carries the gradients of W0, the codes and b0."""
+        npe = 3 + 6 * self.multires
+        W0 = self.lin0.weight
+        Bf = conds.reshape(-1, self.feature_vector_size) @ W0[:, npe:].t() + self.lin0.bias            # [N, 512]
+        W0p = pad_cols(W0[:, :npe], pad4(npe))                                                          # [512, pad4(39)] (a copy: never a deferred sink)
+        spec = getattr(self, "_spec_pe", None)
+        if spec is None:
+            spec = self._spec_pe = MLPSpec.relu_mlp(npe, [L.N for L in self.spec.layers])
+        return spec, W0p, Bf
+
     def forward(self, ps, conds, batch_inds=None, **kwargs):
         ratio = kwargs['ratio']['deformerRatio']
         ws = resolve_band_weights(self.multires, ratio)
+        if batch_inds is None and HOIST_FRAME_CODE and ps.dim() == 3:
+            spec, W0p, Bf = self.hoisted_first_layer(conds)
+            Ws, bs = self.packed_weights()
+            outs = []
+            for f in range(ps.shape[0]):
+                A0 = embed_rows(ps[f], self.multires, ws)
+                outs.append(mlp_apply(spec, A0, [W0p] + Ws[1:], [Bf[f]] + bs[1:]))
+            self.offset = torch.stack(outs, 0)
+            return ps[..., :3] + self.offset
         if batch_inds is not None:
             flat, index, seg = ps, batch_inds, 0
         else:                                        # [N, V, 3] with one code per frame
@@ -427,26 +455,30 @@ class TranslatorValueJacobian(torch.autograd.Function):
     First-order differentiable (what the deformation regulariser needs, network.py:565-582)."""
 
     @staticmethod
-    def forward(ctx, tr, ratio, x, conds, index, segment, *wb):
+    def forward(ctx, tr, ratio, x, conds, index, segment, spec, *wb):
+        """`spec` None: the translator's own layer table with the per-frame code as input columns (`conds`, `index`);
+        otherwise a table whose first layer takes PE(p) only (conds None; the code product sits in the first bias, see
+        MLPTranslator.hoisted_first_layer)."""
         from .. import mlp_engine as me
         from .Embedder import band_weight_tensor
-        nl = len(tr.spec.layers)
+        spec = spec or tr.spec
+        nl = len(spec.layers)
         Ws, bs = list(wb[:nl]), list(wb[nl:])
         flat = x.reshape(-1, 3).contiguous().float()
         P = flat.shape[0]
         wt, _ = band_weight_tensor(resolve_band_weights(tr.multires, ratio), tr.multires, flat.device)
-        E = tr.feature_vector_size
+        E = 0 if conds is None else tr.feature_vector_size
         ldo = me.pad4(3 + 6 * tr.multires + E)
         A0 = torch.empty((P * 4, ldo), dtype=torch.float32, device=flat.device)
-        cd = conds.reshape(-1, E).contiguous().float()
+        cd = None if conds is None else conds.reshape(-1, E).contiguous().float()
         with torch.cuda.device(flat.device):
-            _lib.call("sr_pe_embed", _lib.ptr(flat), P, tr.multires, _lib.ptr(wt), _lib.ptr(cd), cd.stride(0), E, _lib.ptr(index), 4,
-                      _lib.ptr(A0), ldo, _lib.stream_of(flat))
-            acts = me.forward(tr.spec, A0, Ws, bs, 4)
+            _lib.call("sr_pe_embed", _lib.ptr(flat), P, tr.multires, _lib.ptr(wt), _lib.ptr(cd), 0 if cd is None else cd.stride(0), E,
+                      _lib.ptr(index), 4, _lib.ptr(A0), ldo, _lib.stream_of(flat))
+            acts = me.forward(spec, A0, Ws, bs, 4)
         out = acts[-1].view(P, 4, -1)[:, :, :3]
         d = flat + out[:, 0]
         J = out[:, 1:4].transpose(1, 2) + torch.eye(3, device=flat.device)         # J[p, r, c] = delta + d off_r / d x_c
-        ctx.tr, ctx.wt, ctx.segment, ctx.n_extra, ctx.xshape = tr, wt, segment, cd.shape[0], x.shape
+        ctx.tr, ctx.wt, ctx.segment, ctx.n_extra, ctx.xshape, ctx.spec, ctx.E = tr, wt, segment, 0 if cd is None else cd.shape[0], x.shape, spec, E
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(flat, index, A0, *wb, *acts[:-1])
         return d.view(x.shape), J
@@ -454,24 +486,24 @@ class TranslatorValueJacobian(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dbar, Jbar):
         from .. import mlp_engine as me
-        tr = ctx.tr
-        nl = len(tr.spec.layers)
+        tr, spec = ctx.tr, ctx.spec
+        nl = len(spec.layers)
         saved = ctx.saved_tensors
         flat, index, A0 = saved[0], saved[1], saved[2]
         wb, acts = saved[3:3 + 2 * nl], list(saved[3 + 2 * nl:])
         Ws = list(wb[:nl])
         P = flat.shape[0]
         if dbar is None and Jbar is None:
-            return (None,) * (6 + 2 * nl)
+            return (None,) * (7 + 2 * nl)
         ybar = torch.zeros((P, 4, 4), dtype=torch.float32, device=flat.device)
         if dbar is not None:
             ybar[:, 0, :3] = dbar.reshape(-1, 3)
         if Jbar is not None:
             ybar[:, 1:4, :3] = Jbar.transpose(1, 2)
-        WTs = [me.transposed_of(Ws[l], tr.spec.layers[l].K) for l in range(nl)]
+        WTs = [me.transposed_of(Ws[l], spec.layers[l].K) for l in range(nl)]
         acts_full = acts + [None]
-        need_par = any(ctx.needs_input_grad[6:])
-        A0bar, dWs, dbs = me.reverse(tr.spec, A0, WTs, acts_full, ybar.view(P * 4, 4), 4, True, need_par, Ws, list(wb[nl:]))
+        need_par = any(ctx.needs_input_grad[7:])
+        A0bar, dWs, dbs = me.reverse(spec, A0, WTs, acts_full, ybar.view(P * 4, 4), 4, True, need_par, Ws, list(wb[nl:]))
         if not need_par:
             dWs, dbs = [None] * nl, [None] * nl
         xbar = torch.empty_like(flat)
@@ -481,14 +513,14 @@ class TranslatorValueJacobian(torch.autograd.Function):
         if dbar is not None:
             xbar = xbar + dbar.reshape(-1, 3)
         gcond = None
-        if ctx.needs_input_grad[3]:
-            E = tr.feature_vector_size
+        if ctx.needs_input_grad[3] and ctx.E:
+            E = ctx.E
             ge = A0bar.view(P, 4, -1)[:, 0, 3 + 6 * tr.multires:3 + 6 * tr.multires + E]
             if ctx.segment:
                 gcond = ge.reshape(ctx.n_extra, ctx.segment, E).sum(1)
             else:
                 gcond = torch.zeros((ctx.n_extra, E), device=flat.device).index_add(0, index, ge)
-        return (None, None, xbar.view(ctx.xshape), gcond, None, None) + tuple(dWs) + tuple(dbs)
+        return (None, None, xbar.view(ctx.xshape), gcond, None, None, None) + tuple(dWs) + tuple(dbs)
 
 
 def translator_value_jacobian(tr, ps, conds, batch_inds, ratio):
@@ -500,4 +532,11 @@ def translator_value_jacobian(tr, ps, conds, batch_inds, ratio):
         index = torch.arange(ps.shape[0], device=ps.device).repeat_interleave(ps.shape[1])
         seg = ps.shape[1]
     Ws, bs = tr.packed_weights()
-    return TranslatorValueJacobian.apply(tr, r, ps, conds, index, seg, *Ws, *bs)
+    if batch_inds is None and HOIST_FRAME_CODE and ps.dim() == 3:            # frame-major batch: code product as a per-frame bias
+        spec, W0p, Bf = tr.hoisted_first_layer(conds)
+        ds_, Js_ = [], []
+        for f in range(ps.shape[0]):
+            d_f, J_f = TranslatorValueJacobian.apply(tr, r, ps[f].contiguous(), None, None, 0, spec, W0p, *Ws[1:], Bf[f], *bs[1:])
+            ds_.append(d_f); Js_.append(J_f)
+        return torch.stack(ds_, 0), torch.cat(Js_, 0)
+    return TranslatorValueJacobian.apply(tr, r, ps, conds, index, seg, None, *Ws, *bs)

@@ -62,6 +62,8 @@ class ImplicitNetwork(nn.Module):
         self.rendcond = None
 
     def packed_weights(self):
+        from ..mlp_engine import refresh_packs
+        refresh_packs([getattr(self, "lin" + str(l)) for l in range(len(self.spec.layers))])
         Ws, bs = [], []
         for l, L in enumerate(self.spec.layers):
             lin = getattr(self, "lin" + str(l))

@@ -323,11 +323,11 @@ class OptimNetwork(nn.Module):
                 debug.update(batch_inds=batch_inds, row_inds=row_inds, col_inds=col_inds, seeds=initTmpPs.clone())
             selected = torch.cuda.Event()
             selected.record(side)
-        # The refiner (no autograd) follows the template branch on the main stream (refiner_stream = "main", the default) or stays on
-        # the side stream and runs CONCURRENTLY with it ("side").  Measured on the convergent coarse scene: 58.2 ms / iteration
-        # against 56.2 -- the concurrent form is 3.5 % faster, but the refiner's layer GEMMs then share the CUs with the template
-        # branch's and no per-kernel duration (events or rocprof) is a kernel's own any more; the default keeps the accounting clean.
-        on_side = getattr(self, 'refiner_stream', 'main') == 'side'
+        # The refiner (no autograd) stays on the side stream and runs CONCURRENTLY with the template branch (refiner_stream = "side",
+        # the default: its short layer launches fill the gaps and tails of the template branch's large kernels, ~2 ms / iteration),
+        # or follows it on the main stream ("main": what bench.py's instrumented pass uses, because with two streams of GEMMs no
+        # per-kernel duration -- events or rocprof -- is a kernel's own any more).
+        on_side = getattr(self, 'refiner_stream', 'side') == 'side'
         rstream = side if on_side else main
         if not on_side:
             main.wait_event(selected)

@@ -260,3 +260,75 @@ def test_sdf_forward_backward_at_96k_rows_vs_fp64():
     for n, a, b in zip(names, ours[1:], ref[1:]):
         # sums over 98k rows: fp32 accumulation (fixed slab order) against float64
         torch.testing.assert_close(a.cpu(), b.float(), rtol=2e-4, atol=2e-5 * max(1e-3, float(b.abs().max())), msg=lambda m, n=n: n + ": " + m)
+
+
+def test_fused_pack_refresh_and_fused_flush_match_torch_weight_norm():
+    """One-launch refresh of all packed weights after an optimizer step (sr_pack_weights) and the one-launch weight-norm
+    backward of the deferred gradients (sr_unpack_grads), against torch's own weight_norm (network.py:65-66) in float64."""
+    import torch.nn as nn
+    from selfreconcode_amd import mlp_engine as me
+    torch.manual_seed(3)
+    dev = "cuda:0"
+    lins = [nn.utils.weight_norm(nn.Linear(39, 256)).to(dev), nn.utils.weight_norm(nn.Linear(256, 217)).to(dev), nn.Linear(217, 3).to(dev)]
+    for l in lins:                      # first pack: per-layer torch path
+        me.pack_linear(l)
+    with torch.no_grad():               # "optimizer step"
+        for l in lins:
+            for p in l.parameters():
+                p.add_(0.05 * torch.randn_like(p))
+    me.refresh_packs(lins)
+    for l in lins:
+        W = me.pack_linear(l)
+        if hasattr(l, "weight_g"):
+            v, g = l.weight_v.double(), l.weight_g.double()
+            ref = v * (g / v.norm(dim=1, keepdim=True))
+        else:
+            ref = l.weight.double()
+        N, K = ref.shape
+        assert W.shape == (N, me.pad4(K))
+        assert torch.allclose(W[:, :K].double(), ref, rtol=0, atol=2e-7 * ref.abs().max().item())
+        assert (W[:, K:] == 0).all()
+        WT = me.transposed_of(W, K)
+        assert torch.equal(WT[:, :N], W[:, :K].t()) and (WT[:, N:] == 0).all()
+
+    # deferred gradients -> parameter gradients
+    me.set_deferred_param_grads(True)
+    try:
+        refs = []
+        for l in lins:
+            W = me.pack_linear(l)
+            sink = me._deferred_sink(W, l.bias)
+            assert sink is not None
+            dW, db, acc = sink
+            assert not acc
+            gW = torch.randn_like(dW); gb = torch.randn_like(db)
+            dW.copy_(gW); db.copy_(gb)
+            K = l.in_features
+            if hasattr(l, "weight_g"):
+                v = l.weight_v.detach().double().requires_grad_(True); g = l.weight_g.detach().double().requires_grad_(True)
+                w = v * (g / v.norm(dim=1, keepdim=True))
+                w.backward(gW[:, :K].double())
+                refs.append((v.grad, g.grad, gb, gW))
+            else:
+                refs.append((gW[:, :K].double(), None, gb, gW))
+        for l in lins:
+            for p in l.parameters():
+                p.grad = None
+        me.flush_param_grads()
+        for twice in range(2):
+            for l, (rv, rg, rb, _) in zip(lins, refs):
+                s = twice + 1
+                v = l.weight_v if hasattr(l, "weight_g") else l.weight
+                assert torch.allclose(v.grad.double(), s * rv, rtol=1e-5, atol=1e-5 * rv.abs().max().item())
+                if rg is not None:
+                    assert torch.allclose(l.weight_g.grad.double(), s * rg, rtol=1e-5, atol=1e-5 * rg.abs().max().item())
+                assert torch.allclose(l.bias.grad, s * rb, rtol=1e-6, atol=1e-6)
+            if twice == 0:              # a second flush of the same values ADDS into the existing gradients
+                for l, (rv, rg, rb, gW) in zip(lins, refs):
+                    W = me.pack_linear(l)
+                    dW, db, acc = me._deferred_sink(W, l.bias)
+                    assert not acc
+                    dW.copy_(gW); db.copy_(rb)
+                me.flush_param_grads()
+    finally:
+        me.set_deferred_param_grads(False)
