@@ -315,6 +315,11 @@ int sr_svd3x3(const float* A, int64_t n, float* U, float* S, float* V, void* str
  * model/RenderNet.py:46-47: W = g v/|v|; g NULL = plain layer): W [N, ldw] zero padded, WT [K, ldwt] = W^T zero padded,
  * norms [N] = |v_n|.  _unpack is the backward: dW [N, lddw] -> gv [N, K] (and gg [N] for weight-normed layers), i.e.
  * aten::_weight_norm_interface_backward; accumulate != 0 adds to gv / gg. */
+/* dst [rows * group, ldd]: row r * group + g = (g == 0 ? a : b)[r, :n] zero padded to `width` columns; group 1 (a only) or 2 (the
+ * (primal, tangent) row interleave of the group-2 GEMMs); a NULL source gives zero rows. */
+int sr_rows_pad(const float* a, int64_t lda, int32_t na, const float* b, int64_t ldb, int32_t nb, int64_t rows, int32_t group, float* dst, int64_t ldd,
+                int32_t width, void* stream);
+
 #define SR_PACK_MAX_LAYERS 16
 typedef struct { const float* v; const float* g; float* W; float* WT; float* norms; int32_t N, K; int64_t ldw, ldwt; } sr_pack_layer;
 typedef struct { int32_t nlayers; sr_pack_layer layer[SR_PACK_MAX_LAYERS]; } sr_pack_table;
@@ -361,6 +366,71 @@ int sr_points_silhouette_bwd(const float* xy_ndc, const float* z, int64_t nimg, 
                              const void* workspace, const float* gmask, float* gxy, void* stream);
 int sr_rasterize_meshes(const float* xy_ndc, const float* z, const int64_t* faces, int64_t nimg, int64_t V, int64_t F, int32_t H, int32_t W,
                         void* zbuf_u64, int64_t* pix_to_face, float* bary, float* zout, void* stream);
+
+/* ---------------------------------------------------------------- fused per-ray / per-vertex tails of one step (csrc/step_ops.hip)
+ * Each pair replaces a block of elementwise torch ops of the reference's training step (and their autograd mirror) with one
+ * launch for the value and one for the gradient.  Reductions are deterministic (fixed summation order, no float atomics).
+ *
+ * Camera (model/CameraMine.py:44-70,129-170,171-262).  All pointers are DEVICE pointers (the intrinsics are learnable
+ * parameters, config.conf:10-15): R [3,3] row-major with p_cam = p R + T, T [3] (NULL = 0), f [2], c [2]; W, H in pixels;
+ * one_minus_inv_w/h = (float)(1 - 1/W), (float)(1 - 1/H) computed on the host as the reference's Python scalars are.
+ *   sr_cam_project_ndc_fwd: ps [n,3] -> xy [n,2] in pytorch3d's NDC frame (x = f0/(W/2) X/Z + 1 - 1/W - c0/(W/2)), z [n] = view depth.
+ *   sr_cam_project_ndc_bwd: gxy / gz (either may be NULL) -> gps [n,3] (NULL: skipped) and, when `partial`
+ *     ([sr_step_param_blocks(n), 16] scratch) is given, gparams [16] = gR[9] | gT[3] | gf[2] | gc[2].
+ *   sr_cam_view_rays_fwd: pixels [n,3] = (col, row, 1) -> unit world rays normalize([(c0 h - u)/f0, (c1 h - w)/f1, h]) R^T.
+ *   sr_cam_view_rays_bwd: grays -> gparams [16] in the same layout (gT slots untouched = 0). */
+#define SR_STEP_MAX_FRAMES 8
+typedef struct { const float* R; const float* T; const float* f; const float* c; float W, H, one_minus_inv_w, one_minus_inv_h; } sr_camera;
+int sr_step_reduce_blocks(int64_t rows);      /* workgroups (= rows of `partial`, SR_STEP_LOSS_SLOTS - 1 floats each) a loss reduction over `rows` uses */
+int sr_step_param_blocks(int64_t rows);       /* rows of `partial` (16 floats each) of the camera backward kernels */
+int sr_cam_project_ndc_fwd(const float* ps, int64_t n, const sr_camera* cam, float* xy, float* z, void* stream);
+int sr_cam_project_ndc_bwd(const float* ps, int64_t n, const sr_camera* cam, const float* gxy, const float* gz, float* gps, float* partial,
+                           float* gparams, void* stream);
+int sr_cam_view_rays_fwd(const float* pixels, int64_t n, const sr_camera* cam, float* rays, void* stream);
+int sr_cam_view_rays_bwd(const float* pixels, int64_t n, const sr_camera* cam, const float* grays, float* partial, float* gparams, void* stream);
+
+/* Cardinal rays and deformed normals (utils/utils.py:132-169) from the deformation Jacobian J [n,3,3] (J[i][j] = d d_i / d p_j):
+ *   sr_cardinal_rays_fwd: out = normalize(J^-1 v); rows whose |det J| < 1e-4 (FastMinv's rule) keep normalize(v) and ok = 0.
+ *   sr_cardinal_rays_bwd: cotangent of out -> gJ [n,9] = -(J^-T gu)(J^-1 v)^T and gv [n,3] = J^-T gu (either may be NULL; zero on ok = 0 rows,
+ *     where the reference substitutes rays.detach()).
+ *   sr_deformed_normals: out = normalize(J^-T n) (J n on singular rows); no gradient ('test' phase of compute_deformed_normals). */
+int sr_cardinal_rays_fwd(const float* J, const float* v, int64_t n, float* out, uint8_t* ok, void* stream);
+int sr_cardinal_rays_bwd(const float* J, const float* v, int64_t n, const float* gout, float* gJ, float* gv, void* stream);
+int sr_deformed_normals(const float* J, const float* onx, int64_t n, float* out, void* stream);
+
+/* Loss reductions.  out [SR_STEP_LOSS_SLOTS]: out[0] = the loss, out[1 + f] / out[1 + SR_STEP_MAX_FRAMES + f] = the per-frame
+ * numerator / denominator sums the backward reads back as `saved`.  partial: [sr_step_reduce_blocks(rows), SR_STEP_LOSS_SLOTS - 1]
+ * scratch, may be NULL when that is 1.  gloss: device scalar (cotangent of the loss).
+ *   colour (model/network.py:611-618): rays (b, r, c) [P] into gt [N,H,W,3]; mean over frames of the per-frame mean of |gt - colour|_1.
+ *   normal (model/network.py:620-639): gt normal image [N,H,W,3] -> flip diag(-1,1,-1) -> world (R [3,3]) -> unit (valid when
+ *     |.| > 1e-4) -> canonical (J^T), against normalize(nx_raw); weighted != 0 multiplies by clamp(-rays . n_def, 0, 1)^2 with
+ *     n_def = sr_deformed_normals(J, nx_raw) (detached); masked scatter-mean over frames.  _bwd: gnx_raw [P,3], gJ [P,9] (NULL: skipped).
+ *   eikonal (model/network.py:547-549): mean (|g| - 1)^2 over g [n,3].
+ *   def_regu (model/network.py:565-582 + utils/utils.py:48-52): S [n,3] singular values -> mean GM(sum_k log(s_k)^2, c); _bwd goes
+ *     straight to gJ [n,9] = U diag(gS) V^T with the U, V of sr_svd3x3.   sr_svd3x3_bwd: the plain gS -> gJ.
+ *   mask IoU (model/network.py:652-654): masks, gt [N, hw]; mean over frames of 1 - sum(m g) / sum |m + g - m g|. */
+#define SR_STEP_LOSS_SLOTS (1 + 2 * SR_STEP_MAX_FRAMES)
+typedef struct { const int64_t* b; const int64_t* r; const int64_t* c; int64_t P; int32_t N, H, W; } sr_ray_pixels;
+int sr_color_loss_fwd(const sr_ray_pixels* px, const float* colors, const float* gt, float* partial, float* out, void* stream);
+int sr_color_loss_bwd(const sr_ray_pixels* px, const float* colors, const float* gt, const float* saved, const float* gloss, float* gcolors,
+                      void* stream);
+int sr_normal_loss_fwd(const sr_ray_pixels* px, const float* nx_raw, const float* J, const float* gt_normals, const float* R, const float* rays,
+                       int weighted, float* partial, float* out, void* stream);
+int sr_normal_loss_bwd(const sr_ray_pixels* px, const float* nx_raw, const float* J, const float* gt_normals, const float* R, const float* rays,
+                       int weighted, const float* saved, const float* gloss, float* gnx_raw, float* gJ, void* stream);
+int sr_eikonal_loss_fwd(const float* g, int64_t n, float* partial, float* out, void* stream);
+int sr_eikonal_loss_bwd(const float* g, int64_t n, const float* gloss, float* gg, void* stream);
+int sr_def_regu_loss_fwd(const float* S, int64_t n, float c, float* partial, float* out, void* stream);
+int sr_def_regu_loss_bwd(const float* U, const float* S, const float* V, int64_t n, float c, const float* gloss, float* gJ, void* stream);
+int sr_svd3x3_bwd(const float* U, const float* V, const float* gS, int64_t n, float* gJ, void* stream);
+int sr_mask_iou_loss_fwd(const float* masks, const float* gt, int N, int64_t hw, float* partial, float* out, void* stream);
+int sr_mask_iou_loss_bwd(const float* masks, const float* gt, int N, int64_t hw, const float* saved, const float* gloss, float* gmasks, void* stream);
+
+/* Normal equations of the implicit differentiation (model/network.py:702-771): b = [grad_f ; [v]x J] (4x3),
+ * rhs = grad_l^T (b^T b)^-1 b^T with FastMinv's singularity rule (ok = 0, zeros) -> cot_f [n] = -rhs[0], rhs_tail [n,3] = rhs[1:4],
+ * temp [n,3] = rhs[1:4] (-[v]x). */
+int sr_implicit_solve(const float* grad_f, const float* J, const float* v, const float* grad_l, int64_t n, float* cot_f, float* rhs_tail, float* temp,
+                      uint8_t* ok, void* stream);
 
 #ifdef __cplusplus
 }

@@ -85,7 +85,7 @@ def color_normal(sc, TmpPs, rays, bi, rows, cols, dcond, poses, trans, rcond, gt
             cnx = (Ji2.transpose(-2, -1) @ onx.view(-1, 3, 1)).view(-1, 3)
             cnx = torch.where(ok2[:, None], cnx, (J2 @ onx.unsqueeze(-1)).view(-1, 3))
             cnx = cnx / cnx.norm(dim=1, keepdim=True)
-            w = torch.clamp((-rays * cnx.detach()).sum(1), max=1., min=0.) ** 2
+            w = torch.clamp((-rays * cnx.detach()).sum(1).detach(), max=1., min=0.) ** 2           # :623-624: detached, also w.r.t. the rays
         else:
             w = torch.ones(nx.shape[0], dtype=nx.dtype)
         flip = torch.tensor([[-1., 0., 0.], [0., 1., 0.], [0., 0., -1.]], dtype=nx.dtype)
@@ -179,9 +179,13 @@ def cross_matrix(v):
 
 
 def propagate(sc, state, frame_ids, ratio):
-    """propagateTmpPsGrad (network.py:702-814) with fixed cameras: returns (#systems, #invertible)."""
+    """propagateTmpPsGrad (network.py:702-814): returns (#systems, #invertible).  Camera tensors of `sc.cam` that require grad
+    receive the ray / camera-centre terms of :798-813."""
     poses, trans, dcond = sc.poses[frame_ids], sc.trans[frame_ids], sc.dcond[frame_ids]
-    p, v, bi = state['TmpPs'], state['rays'].detach(), state['bi']
+    p, bi = state['TmpPs'], state['bi']
+    v_live = sc.rays(state['cols'], state['rows']) if state['rays'].requires_grad else state['rays']      # :715-718 (graph rebuilt)
+    v = v_live.detach()
+    c_live = orc.cam_pos(sc.cam['R'], sc.cam['T'])
     glp = p.grad
     pd = p.detach().clone().requires_grad_(True)
     f = orc.sdf_forward(sc.sdf, pd, ratio)[0]
@@ -191,8 +195,15 @@ def propagate(sc, state, frame_ids, ratio):
     vx = cross_matrix(v)
     b = torch.cat([gfp.view(-1, 1, 3), vx @ Jd], 1)
     binv, ok = orc.minv3x3(b.permute(0, 2, 1) @ b)
-    rhs = glp.view(-1, 1, 3) @ (binv @ b.permute(0, 2, 1))
+    rhs = (glp.view(-1, 1, 3) @ (binv @ b.permute(0, 2, 1))).detach()
     f2 = orc.sdf_forward(sc.sdf, p.detach(), ratio)[0]
     d2 = sc.deform(p.detach(), dcond, poses, trans, bi, ratio)
-    torch.autograd.backward([f2, d2], [(-rhs[:, :, 0]).reshape(f2.shape), (rhs[:, :, -3:] @ (-vx)).view(-1, 3)])
+    temp = (rhs[:, :, -3:] @ (-vx)).view(-1, 3)
+    outs, cots = [f2, d2], [(-rhs[:, :, 0]).reshape(f2.shape), temp]
+    if v_live.requires_grad:                                   # :798-809
+        dc = d2.detach() - c_live.detach().view(1, 3)
+        outs.append(v_live); cots.append((rhs[:, :, -3:] @ cross_matrix(dc)).view(-1, 3))
+    if c_live.requires_grad:                                   # :811-813
+        outs.append(c_live); cots.append(-temp.sum(0))
+    torch.autograd.backward(outs, cots)
     return ok.numel(), int(ok.sum())

@@ -89,6 +89,19 @@ class SrUnpackTable(ctypes.Structure):
     _fields_ = [("nlayers", ctypes.c_int32), ("layer", SrUnpackLayer * SR_PACK_MAX_LAYERS)]
 
 
+SR_STEP_MAX_FRAMES = 8
+SR_STEP_LOSS_SLOTS = 1 + 2 * SR_STEP_MAX_FRAMES
+
+
+class SrCamera(ctypes.Structure):
+    _fields_ = [("R", _vp), ("T", _vp), ("f", _vp), ("c", _vp), ("W", ctypes.c_float), ("H", ctypes.c_float),
+                ("one_minus_inv_w", ctypes.c_float), ("one_minus_inv_h", ctypes.c_float)]
+
+
+class SrRayPixels(ctypes.Structure):
+    _fields_ = [("b", _vp), ("r", _vp), ("c", _vp), ("P", _i64), ("N", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32)]
+
+
 class SrError(RuntimeError):
     pass
 
@@ -142,9 +155,31 @@ SIGNATURES = {
     "sr_mc_workspace_bytes": [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32],
     "sr_mc_count": [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp],
     "sr_mc_emit": [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp] + [ctypes.c_float] * 6 + [_vp, _vp, _vp],
+    "sr_rows_pad": [_vp, _i64, ctypes.c_int32, _vp, _i64, ctypes.c_int32, _i64, ctypes.c_int32, _vp, _i64, ctypes.c_int32, _vp],
     "sr_pack_weights": [_vp, _vp],
     "sr_unpack_grads": [_vp, _vp],
     "sr_svd3x3": [_vp, _i64, _vp, _vp, _vp, _vp],
+    "sr_step_reduce_blocks": [_i64],
+    "sr_step_param_blocks": [_i64],
+    "sr_cam_project_ndc_fwd": [_vp, _i64, _vp, _vp, _vp, _vp],
+    "sr_cam_project_ndc_bwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sr_cam_view_rays_fwd": [_vp, _i64, _vp, _vp, _vp],
+    "sr_cam_view_rays_bwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp],
+    "sr_cardinal_rays_fwd": [_vp, _vp, _i64, _vp, _vp, _vp],
+    "sr_cardinal_rays_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "sr_deformed_normals": [_vp, _vp, _i64, _vp, _vp],
+    "sr_color_loss_fwd": [_vp, _vp, _vp, _vp, _vp, _vp],
+    "sr_color_loss_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sr_normal_loss_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp],
+    "sr_normal_loss_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp],
+    "sr_eikonal_loss_fwd": [_vp, _i64, _vp, _vp, _vp],
+    "sr_eikonal_loss_bwd": [_vp, _i64, _vp, _vp, _vp],
+    "sr_def_regu_loss_fwd": [_vp, _i64, ctypes.c_float, _vp, _vp, _vp],
+    "sr_def_regu_loss_bwd": [_vp, _vp, _vp, _i64, ctypes.c_float, _vp, _vp, _vp],
+    "sr_svd3x3_bwd": [_vp, _vp, _vp, _i64, _vp, _vp],
+    "sr_mask_iou_loss_fwd": [_vp, _vp, ctypes.c_int32, _i64, _vp, _vp, _vp],
+    "sr_mask_iou_loss_bwd": [_vp, _vp, ctypes.c_int32, _i64, _vp, _vp, _vp, _vp],
+    "sr_implicit_solve": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "sr_points_silhouette_workspace_bytes": [_i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float],
     "sr_points_silhouette_fwd": [_vp, _vp, _i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_int32, _vp, _vp, _vp],
     "sr_points_silhouette_bwd": [_vp, _vp, _i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp, _vp],

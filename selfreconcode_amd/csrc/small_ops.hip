@@ -140,9 +140,34 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(sr_unpack_table t) {
     }
   }
 }
+
+// dst [rows * group, ldd]: row r*group + g = (g == 0 ? a : b)[r, :n] zero padded to `width` columns (a NULL source gives a zero row).
+__global__ __launch_bounds__(256) void rows_pad_kernel(const float* __restrict__ a, int64_t lda, int na, const float* __restrict__ b, int64_t ldb, int nb,
+                                                       int64_t rows, int group, float* __restrict__ dst, int64_t ldd, int width) {
+  const int64_t total = rows * group * (int64_t)width;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / width;
+    const int col = (int)(i - row * width);
+    const int64_t r = row / group;
+    const int g = (int)(row - r * group);
+    const float* src = g == 0 ? a : b;
+    const int n = g == 0 ? na : nb;
+    const int64_t ld = g == 0 ? lda : ldb;
+    dst[row * ldd + col] = (src && col < n) ? src[r * ld + col] : 0.f;
+  }
+}
 }  // namespace
 
 extern "C" {
+int sr_rows_pad(const float* a, int64_t lda, int32_t na, const float* b, int64_t ldb, int32_t nb, int64_t rows, int32_t group, float* dst, int64_t ldd,
+                int32_t width, void* stream) {
+  if (rows < 0 || (group != 1 && group != 2) || width < 1 || ldd < width || na < 0 || nb < 0 || na > width || nb > width) return SR_EINVAL;
+  if (rows == 0) return SR_OK;
+  if (!dst || (a && lda < na) || (b && ldb < nb)) return SR_EINVAL;
+  hipLaunchKernelGGL(rows_pad_kernel, dim3(sr_stream_grid(rows * group * (int64_t)width, 256)), dim3(256), 0, (hipStream_t)stream, a, lda, na, b, ldb, nb,
+                     rows, group, dst, ldd, width);
+  return sr_launch_status();
+}
 int sr_pack_weights(const sr_pack_table* t, void* stream) {
   if (!t || t->nlayers < 1 || t->nlayers > SR_PACK_MAX_LAYERS) return SR_EINVAL;
   for (int l = 0; l < t->nlayers; ++l) {

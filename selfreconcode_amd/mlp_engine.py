@@ -258,6 +258,28 @@ def pad_cols(t, width):
     return torch.nn.functional.pad(t, (0, width - t.shape[1]))
 
 
+def rows_pad(a, width, b=None, pair=False):
+    """No-autograd helper of the Functions below: `a` [R, n] -> [R, width] zero padded in one launch (returned as is when it
+    already has that shape and unit column stride / padded pitch); with `pair`, the group-2 interleave [2R, width] of the rows
+    (a, b), where None stands for zero rows."""
+    ref = a if a is not None else b
+    R = ref.shape[0]
+    if not pair and a.shape[1] == width and a.stride(1) == 1 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0:
+        return a
+    srcs = []
+    for t in (a, b):
+        if t is not None and (t.stride(1) != 1 or t.dtype != torch.float32):
+            t = t.contiguous().float()
+        srcs.append(t)
+    a, b = srcs
+    out = torch.empty((R * (2 if pair else 1), width), dtype=torch.float32, device=ref.device)
+    with torch.cuda.device(ref.device):
+        _lib.call("sr_rows_pad", _lib.ptr(a), 0 if a is None else a.stride(0), 0 if a is None else min(a.shape[1], width),
+                  _lib.ptr(b), 0 if b is None else b.stride(0), 0 if b is None else min(b.shape[1], width),
+                  R, 2 if pair else 1, _lib.ptr(out), width, width, _lib.stream_of(ref))
+    return out
+
+
 def interleave(rows):
     """[R,K] x g -> [g*R, K] with sample-major interleaving (primal, tangent_1, ...)."""
     return torch.stack(rows, dim=1).reshape(rows[0].shape[0] * len(rows), rows[0].shape[1])
@@ -319,7 +341,7 @@ class MLPCoreBackward(torch.autograd.Function):
         nl = len(spec.layers)
         Ws, bs, acts = list(rest[:nl]), list(rest[nl:2 * nl]), list(rest[2 * nl:])
         NL = spec.layers[-1].N
-        yb = pad_cols(ybar, pad4(NL))
+        yb = rows_pad(ybar, pad4(NL))
         WTs = [transposed_of(Ws[l], spec.layers[l].K) for l in range(nl)]
         A0bar, dWs, dbs = reverse(spec, A0, WTs, acts, yb, 1, need_in, need_par, Ws, bs)
         ctx.spec = spec
@@ -328,7 +350,7 @@ class MLPCoreBackward(torch.autograd.Function):
         if not need_par:
             dWs, dbs = [None] * nl, [None] * nl
         if A0bar is not None and A0bar.shape[1] != A0.shape[1]:
-            A0bar = pad_cols(A0bar[:, :spec.K0], A0.shape[1])
+            A0bar = rows_pad(A0bar[:, :spec.K0], A0.shape[1])
         return (A0bar,) + tuple(dWs) + tuple(dbs)
 
     @staticmethod
@@ -347,18 +369,17 @@ class MLPCoreBackward(torch.autograd.Function):
         NL = spec.layers[-1].N
         R = A0.shape[0]
         # group-2 augmented forward: rows (a0, U)
-        A0i = interleave([A0, pad_cols(U, A0.shape[1])])
+        A0i = rows_pad(A0, A0.shape[1], U, pair=True)                  # rows (a0, U), U zero padded to the pitch of A0
         acts2 = forward(spec, A0i, Ws, bs, 2)
         ydot = acts2[-1].view(R, 2, -1)[:, 1, :NL]                     # d S / d ybar
-        yb = pad_cols(ybar, pad4(NL))
-        ybi = interleave([torch.zeros_like(yb), yb])                    # cotangent only on the tangent output
+        ybi = rows_pad(None, pad4(NL), ybar, pair=True)                 # cotangent only on the tangent output
         WTs = [transposed_of(Ws[l], spec.layers[l].K) for l in range(nl)]
         need_in = ctx.needs_input_grad[3]
         need_par = any(ctx.needs_input_grad[5:5 + 2 * nl])
         A0bar2, dWs, dbs = reverse(spec, A0i, WTs, acts2, ybi, 2, need_in, need_par, Ws, bs)
         gA0 = A0bar2.view(R, 2, -1)[:, 0, :] if A0bar2 is not None else None
         if gA0 is not None and gA0.shape[1] != A0.shape[1]:
-            gA0 = pad_cols(gA0[:, :spec.K0], A0.shape[1])
+            gA0 = rows_pad(gA0[:, :spec.K0], A0.shape[1])
         return (None, None, None, gA0, ydot.contiguous()) + tuple(dWs) + tuple(dbs) + (None,) * (nl - 1)
 
 
@@ -406,6 +427,7 @@ class PackWeightNorm(torch.autograd.Function):
         e = _pack_entry(id(v), _sig(v, g), build)
         e["src"] = (v, g)
         ctx.save_for_backward(v, g, e["norms"])
+        ctx.set_materialize_grads(False)      # deferred mode hands back None for every use: no zero tensor, no weight-norm backward of zeros
         return e["W"].detach()
 
     @staticmethod
@@ -431,6 +453,7 @@ class PackPlain(torch.autograd.Function):
         e = _pack_entry(id(w), _sig(w), build)
         e["src"] = (w,)
         ctx.K = K
+        ctx.set_materialize_grads(False)
         return e["W"].detach()
 
     @staticmethod

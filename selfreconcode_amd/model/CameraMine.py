@@ -4,6 +4,8 @@ RectifiedPerspectiveCameras.view_rays / cam_pos / project / angThreshold
 import numpy as np
 import torch
 
+from .. import step_ops
+
 
 class RectifiedPerspectiveCameras:
     def __init__(self, focal_length, principal_point, R, T, image_size, device=None):
@@ -21,6 +23,8 @@ class RectifiedPerspectiveCameras:
     def view_rays(self, ps, cam_id=0):
         """ps [P,3] = (col, row, 1): v = normalize([(cx-u)/fx, (cy-w)/fy, 1]) R^T."""
         f, c = self.focal_length[cam_id], self.principal_point[cam_id]
+        if step_ops.ENABLED_CAMERA and ps.is_cuda and ps.dim() == 2:
+            return step_ops.ViewRays.apply(ps, self.R[cam_id], f, c)
         rays = torch.stack([-ps[:, 0] / f[0] + ps[:, 2] * c[0] / f[0], -ps[:, 1] / f[1] + ps[:, 2] * c[1] / f[1], ps[:, 2]], dim=1)
         rays = rays / torch.norm(rays, p=2, dim=1, keepdim=True)
         return rays.matmul(self.R[cam_id].transpose(0, 1))
@@ -37,6 +41,8 @@ class RectifiedPerspectiveCameras:
         get_projection_transform with screen-space intrinsics (model/CameraMine.py:44-70, _get_sfm_calibration_matrix
         :171-262: fx_ndc = fx / (W/2), px_ndc = 1 - 1/W - cx / (W/2)) followed by the rasterisers' `z = z_view` override."""
         W, H = float(self.image_size[cam_id, 0]), float(self.image_size[cam_id, 1])
+        if step_ops.ENABLED_CAMERA and ps.is_cuda:
+            return step_ops.ProjectNDC.apply(ps, self.R[cam_id], self.T[cam_id], self.focal_length[cam_id], self.principal_point[cam_id], W, H)
         pc = ps.matmul(self.R[cam_id]) + self.T[cam_id].view(1, 3)
         f, c = self.focal_length[cam_id], self.principal_point[cam_id]
         x = (f[0] / (W / 2.)) * pc[..., 0] / pc[..., 2] + (1. - 1. / W - c[0] / (W / 2.))
@@ -49,8 +55,8 @@ class RectifiedPerspectiveCameras:
     def angThreshold(self, pixoffset=0.4, cam_id=0):
         """Smallest angle (degrees) subtended by `pixoffset` pixels at the four image borders."""
         W, H = float(self.image_size[cam_id, 0]), float(self.image_size[cam_id, 1])
-        cx, cy = float(self.principal_point[cam_id, 0]), float(self.principal_point[cam_id, 1])
-        fx, fy = float(self.focal_length[cam_id, 0]), float(self.focal_length[cam_id, 1])
+        cx, cy = (float(t) for t in self.principal_point[cam_id].detach())
+        fx, fy = (float(t) for t in self.focal_length[cam_id].detach())
 
         def ang(a, b):
             a, b = torch.tensor(a), torch.tensor(b)

@@ -80,9 +80,9 @@ class MLPTranslator(nn.Module):
             spec, W0p, Bf = self.hoisted_first_layer(conds)
             Ws, bs = self.packed_weights()
             outs = []
-            for f in range(ps.shape[0]):
-                A0 = embed_rows(ps[f], self.multires, ws)
-                outs.append(mlp_apply(spec, A0, [W0p] + Ws[1:], [Bf[f]] + bs[1:]))
+            for p_f, B_f in zip(ps.unbind(0), Bf.unbind(0)):                   # unbind: ONE backward node (a stack) instead of a zero-fill + copy per frame
+                A0 = embed_rows(p_f, self.multires, ws)
+                outs.append(mlp_apply(spec, A0, [W0p] + Ws[1:], [B_f] + bs[1:]))
             self.offset = torch.stack(outs, 0)
             return ps[..., :3] + self.offset
         if batch_inds is not None:
@@ -535,8 +535,8 @@ def translator_value_jacobian(tr, ps, conds, batch_inds, ratio):
     if batch_inds is None and HOIST_FRAME_CODE and ps.dim() == 3:            # frame-major batch: code product as a per-frame bias
         spec, W0p, Bf = tr.hoisted_first_layer(conds)
         ds_, Js_ = [], []
-        for f in range(ps.shape[0]):
-            d_f, J_f = TranslatorValueJacobian.apply(tr, r, ps[f].contiguous(), None, None, 0, spec, W0p, *Ws[1:], Bf[f], *bs[1:])
+        for p_f, B_f in zip(ps.unbind(0), Bf.unbind(0)):                       # unbind: ONE backward node (a stack) instead of a zero-fill + copy per frame
+            d_f, J_f = TranslatorValueJacobian.apply(tr, r, p_f.contiguous(), None, None, 0, spec, W0p, *Ws[1:], B_f, *bs[1:])
             ds_.append(d_f); Js_.append(J_f)
         return torch.stack(ds_, 0), torch.cat(Js_, 0)
     return TranslatorValueJacobian.apply(tr, r, ps, conds, index, seg, None, *Ws, *bs)

@@ -20,6 +20,17 @@ def band_weight_tensor(ws, multires, device):
     return t, key[0]
 
 
+_FCACHE = {}
+
+
+def _band_frequencies(L, device, dtype):
+    key = (L, str(device), dtype)
+    f = _FCACHE.get(key)
+    if f is None:
+        f = _FCACHE[key] = (2.0 ** torch.arange(L, device=device, dtype=dtype)).view(1, L, 1)
+    return f
+
+
 class PEFunction(torch.autograd.Function):
     """A0[P, pad4(3+6L+E)] = [x | PE_L(x) | extra[index] | 0].  The backward is written with
     differentiable torch ops on the saved OUTPUT (d sin = f cos, d cos = -f sin are again columns
@@ -62,7 +73,7 @@ class PEFunction(torch.autograd.Function):
         if L > 0 and gx is not None and torch.is_grad_enabled():
             Eb = out[:, 3:3 + 6 * L].reshape(P, L, 2, 3)
             gb = g[:, 3:3 + 6 * L].reshape(P, L, 2, 3)
-            f = (2.0 ** torch.arange(L, device=out.device, dtype=out.dtype)).view(1, L, 1)
+            f = _band_frequencies(L, out.device, out.dtype)
             gx = gx + ((Eb[:, :, 1] * gb[:, :, 0] - Eb[:, :, 0] * gb[:, :, 1]) * f).sum(1)
         gextra = None
         if E > 0 and ctx.needs_input_grad[3]:

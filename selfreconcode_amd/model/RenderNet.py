@@ -5,7 +5,7 @@ import torch.nn as nn
 
 from .Embedder import embed_rows
 from .network import effective_weight
-from ..mlp_engine import MLPSpec, mlp_apply, pad_cols, pad4, pack_linear
+from ..mlp_engine import MLPSpec, mlp_apply, pad_cols, pad4, pack_linear, refresh_packs
 from ..utils.utils import resolve_band_weights
 
 
@@ -30,13 +30,14 @@ class RenderingNetwork_view_norm(nn.Module):
         ratio = ratio['renderRatio']
         nv = 3 + 6 * self.multires_v
         v = embed_rows(view_dirs, self.multires_v, resolve_band_weights(self.multires_v, ratio))[:, :nv]
-        x = torch.cat([points, v, normals, feature_vectors], dim=-1)
-        x = pad_cols(x, pad4(x.shape[1]))
-        Ws, bs = [], []
-        for l, L in enumerate(self.spec.layers):
-            lin = getattr(self, "lin" + str(l))
-            Ws.append(pack_linear(lin))
-            bs.append(lin.bias)
+        width = points.shape[1] + nv + normals.shape[1] + feature_vectors.shape[1]
+        parts = [points, v, normals, feature_vectors]
+        if pad4(width) != width:                  # the row pitch the GEMM wants, as a fifth block of the same cat (no separate pad pass)
+            parts.append(points.new_zeros((points.shape[0], pad4(width) - width)))
+        x = torch.cat(parts, dim=-1)
+        lins = [getattr(self, "lin" + str(l)) for l in range(len(self.spec.layers))]
+        refresh_packs(lins)                       # one launch for all stale layers after an optimizer step
+        Ws, bs = [pack_linear(lin) for lin in lins], [lin.bias for lin in lins]
         return torch.tanh(mlp_apply(self.spec, x, Ws, bs))
 
 

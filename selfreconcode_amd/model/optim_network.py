@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from .. import dist as srdist
 from .. import mlp_engine
+from .. import step_ops
 from ..ext import MCGpu
 from ..ext.FastMinv import Fast3x3Minv
 from ..ops import singular_values_3x3, points_silhouette, rasterize_meshes
@@ -432,6 +433,8 @@ class OptimNetwork(nn.Module):
         pts.requires_grad_()
         pred = self.sdf(pts, ratio, sdf_only=True)
         grad = self.sdf.gradient(pts, pred)
+        if step_ops.ENABLED and grad.is_cuda and grad.shape[0] > 0:
+            return step_ops.EikonalLoss.apply(grad)
         return ((grad.norm(2, dim=-1) - 1) ** 2).mean()
 
     def loss_def_regu(self, pts, d_cond, N, ratio, noise_local=None):
@@ -439,6 +442,8 @@ class OptimNetwork(nn.Module):
         pts = torch.cat([pts, pts + noise_local * 0.01], dim=0).view(1, -1, 3).expand(N, -1, 3)
         from .Deformer import translator_value_jacobian
         _, Jacobs = translator_value_jacobian(self.deformer.defs[0], pts.contiguous(), d_cond, None, ratio)   # forward-mode Jacobian
+        if step_ops.ENABLED and Jacobs.is_cuda and Jacobs.numel() > 0:
+            return step_ops.DefReguLoss.apply(Jacobs, self.conf.get_float('def_regu.c'))
         s = torch.log(singular_values_3x3(Jacobs))
         return U.GMRobustError((s * s).sum(1), self.conf.get_float('def_regu.c'), True).mean()
 
@@ -452,6 +457,7 @@ class OptimNetwork(nn.Module):
     def loss_color_normal(self, datas, gtCs, cameras, defconds, rendcond, ratio, N):
         device = self.TmpPs.device
         total = 0.
+        fused = step_ops.frames_supported(N) and self.TmpPs.is_cuda
         sdfs = self.sdf(self.TmpPs, ratio)
         with mlp_engine.input_grads_only():
             nx = torch.autograd.grad(sdfs, self.TmpPs, torch.ones_like(sdfs), retain_graph=True, create_graph=True)[0]
@@ -464,32 +470,42 @@ class OptimNetwork(nn.Module):
         if self.conf.get_float('color_weight') > 0.:
             colors = U.compute_netRender_color(self.netRender, self.TmpPs, defVs, nx, crays, self.sdf.rendcond,
                                                None if rendcond is None else rendcond[self.batch_inds], ratio)
-            color_loss = (gtCs[self.batch_inds, self.row_inds, self.col_inds, :] - colors).abs().sum(1)
-            color_loss = scatter_mean(color_loss, self.batch_inds, N).mean()
+            if fused:
+                color_loss = step_ops.ColorLoss.apply(colors, gtCs, self.batch_inds, self.row_inds, self.col_inds)
+            else:
+                color_loss = (gtCs[self.batch_inds, self.row_inds, self.col_inds, :] - colors).abs().sum(1)
+                color_loss = scatter_mean(color_loss, self.batch_inds, N).mean()
             self.info['color_loss'] = color_loss.detach()
             total = total + self.conf.get_float('color_weight') * color_loss
         if 'normal' in datas and 'normal_weight' in self.conf and self.conf.get_float('normal_weight') > 0.:
-            if 'weighted_normal' in self.conf and self.conf.get_bool('weighted_normal'):
-                cnx, _ = U.compute_deformed_normals(self.sdf, self.deformer, self.TmpPs, defconds, self.batch_inds, ratio, 'test', cache=jac, onx=nx_raw)
-                weights = torch.clamp((-self.rays * cnx.detach()).sum(1).detach(), max=1., min=0.) ** 2
+            weighted = 'weighted_normal' in self.conf and self.conf.get_bool('weighted_normal')
+            if fused and not cameras.R.requires_grad:
+                # gather of the ground-truth normals, flip, rotation into world space, J^T, the |.| of the difference to the unit SDF
+                # gradient, the detached weights clamp(-v . n_deformed, 0, 1)^2 and the masked scatter-mean: one kernel each way
+                normal_loss = step_ops.NormalLoss.apply(nx_raw, jac['J'], datas['normal'].to(device), cameras.R[0], self.rays, weighted,
+                                                        self.batch_inds, self.row_inds, self.col_inds)
             else:
-                weights = torch.ones(nx.shape[0], device=device)
-            gtnormals = datas['normal'].to(device)[self.batch_inds, self.row_inds, self.col_inds, :]
-            if getattr(self, "_flip", None) is None or self._flip.device != device:
-                self._flip = torch.tensor([[-1., 0., 0.], [0., 1., 0.], [0., 0., -1.]], device=device)      # cached: an H2D copy is a sync point
-            flip = self._flip
-            gtnormals = gtnormals.view(-1, 3) @ (cameras.R[0] @ flip).t()
-            gtnorms = gtnormals.norm(dim=1, keepdim=True)
-            valid_mask = (gtnorms > 0.0001)[..., 0]
-            gtnormals = torch.where(valid_mask[:, None], gtnormals / gtnorms.clamp(min=1e-12), gtnormals)
-            grad_d_p = jac['J']
-            gtnormals = U.small_matvec(grad_d_p.transpose(-2, -1), gtnormals.view(-1, 3))
-            normal_loss = (gtnormals - nx).norm(2, dim=1) * weights
-            # scatter-mean over the valid rows without materialising the subset (no host sync): masked sums / masked counts
-            zero = torch.zeros((), dtype=normal_loss.dtype, device=device)
-            ssum = torch.zeros(N, dtype=normal_loss.dtype, device=device).index_add(0, self.batch_inds, torch.where(valid_mask, normal_loss, zero))
-            scnt = torch.zeros(N, dtype=normal_loss.dtype, device=device).index_add(0, self.batch_inds, valid_mask.to(normal_loss.dtype))
-            normal_loss = (ssum / scnt.clamp(min=1)).mean()
+                if weighted:
+                    cnx, _ = U.compute_deformed_normals(self.sdf, self.deformer, self.TmpPs, defconds, self.batch_inds, ratio, 'test', cache=jac, onx=nx_raw)
+                    weights = torch.clamp((-self.rays * cnx.detach()).sum(1).detach(), max=1., min=0.) ** 2
+                else:
+                    weights = torch.ones(nx.shape[0], device=device)
+                gtnormals = datas['normal'].to(device)[self.batch_inds, self.row_inds, self.col_inds, :]
+                if getattr(self, "_flip", None) is None or self._flip.device != device:
+                    self._flip = torch.tensor([[-1., 0., 0.], [0., 1., 0.], [0., 0., -1.]], device=device)      # cached: an H2D copy is a sync point
+                flip = self._flip
+                gtnormals = gtnormals.view(-1, 3) @ (cameras.R[0] @ flip).t()
+                gtnorms = gtnormals.norm(dim=1, keepdim=True)
+                valid_mask = (gtnorms > 0.0001)[..., 0]
+                gtnormals = torch.where(valid_mask[:, None], gtnormals / gtnorms.clamp(min=1e-12), gtnormals)
+                grad_d_p = jac['J']
+                gtnormals = U.small_matvec(grad_d_p.transpose(-2, -1), gtnormals.view(-1, 3))
+                normal_loss = (gtnormals - nx).norm(2, dim=1) * weights
+                # scatter-mean over the valid rows without materialising the subset (no host sync): masked sums / masked counts
+                zero = torch.zeros((), dtype=normal_loss.dtype, device=device)
+                ssum = torch.zeros(N, dtype=normal_loss.dtype, device=device).index_add(0, self.batch_inds, torch.where(valid_mask, normal_loss, zero))
+                scnt = torch.zeros(N, dtype=normal_loss.dtype, device=device).index_add(0, self.batch_inds, valid_mask.to(normal_loss.dtype))
+                normal_loss = (ssum / scnt.clamp(min=1)).mean()
             self.info['normal_loss'] = normal_loss.detach()
             total = total + self.conf.get_float('normal_weight') * normal_loss
         return total
@@ -497,7 +513,10 @@ class OptimNetwork(nn.Module):
     def computeTmpPcLoss(self, defTmpVs, defconds, masks, gtMs, ratio):
         """Mask IoU loss (+ deformation-consistency) -> inner backward + template SGD step -> |f(TmpVs)| term."""
         N = gtMs.shape[0]
-        mask_loss = (1. - (masks * gtMs).view(N, -1).sum(1) / (masks + gtMs - masks * gtMs).abs().view(N, -1).sum(1)).mean()
+        if step_ops.frames_supported(N) and masks.is_cuda:
+            mask_loss = step_ops.MaskIoULoss.apply(masks, gtMs)
+        else:
+            mask_loss = (1. - (masks * gtMs).view(N, -1).sum(1) / (masks + gtMs - masks * gtMs).abs().view(N, -1).sum(1)).mean()
         self.info['pc_loss']['mask_loss'] = mask_loss.detach()
         loss = mask_loss * (self.conf.get_float('pc_weight.mask_weight') if 'pc_weight.mask_weight' in self.conf else 1.)
         for name in ('laplacian_weight', 'edge_weight', 'norm_weight'):
@@ -556,23 +575,31 @@ class OptimNetwork(nn.Module):
         d, grad_d_p = U.deformed_points_and_jacobian(self.deformer, p, defconds, self.batch_inds, ratio, True)
         grad_d_p = grad_d_p.detach()                                   # graphs of f and d are kept: they are back-propagated below
         opt_defconds = [t for t in (d_cond, poses, trans) if t.requires_grad]
-        v_cross = cross_matrix(v)
-        b = torch.cat([grad_f_p.view(-1, 1, 3), U.small_matmul(v_cross, grad_d_p)], dim=1)
-        btb = U.small_matmul(b.permute(0, 2, 1), b)
-        btb_inv, check = Fast3x3Minv(btb.contiguous())
-        self.info['invInfo'] = (check.numel(), check.sum())
-        rhs_1 = U.small_matmul(grad_l_p.view(-1, 1, 3), U.small_matmul(btb_inv, b.permute(0, 2, 1)))        # [P,1,4]
         # The reference builds a surrogate loss sum(param * grad) from three autograd.grad calls and back-propagates it
         # (network.py:773-814); that adds `grad` to every parameter's .grad, which is exactly one backward of
         # (f, d) with the cotangents (-rhs_f, temp).
         # (The reference evaluates f and d a second time at p.detach() for this; the weights have not moved since the evaluations
         # above, so those graphs are reused and the backward is restricted to the learnable leaves -- p itself gets no gradient.)
         f2, d2 = f, d
-        temp = U.small_matmul(rhs_1[:, :, -3:], -v_cross).view(-1, 3)
-        outs, cots = [f2, d2], [(-rhs_1[:, :, 0]).reshape(f2.shape).detach(), temp.detach()]
+        if step_ops.ENABLED and p.is_cuda:
+            # b = [grad f ; [v]x J], (b^T b)^-1 (FastMinv's rule), rhs = grad_l^T (b^T b)^-1 b^T, rhs[1:4] (-[v]x): one kernel
+            cot_f, rhs_tail, temp, check = step_ops.implicit_solve(grad_f_p, grad_d_p, v, grad_l_p)
+            self.info['invInfo'] = (check.numel(), check.sum())
+            cot_f, rhs_tail = cot_f.view(f2.shape), rhs_tail.view(-1, 1, 3)
+        else:
+            v_cross = cross_matrix(v)
+            b = torch.cat([grad_f_p.view(-1, 1, 3), U.small_matmul(v_cross, grad_d_p)], dim=1)
+            btb = U.small_matmul(b.permute(0, 2, 1), b)
+            btb_inv, check = Fast3x3Minv(btb.contiguous())
+            self.info['invInfo'] = (check.numel(), check.sum())
+            rhs_1 = U.small_matmul(grad_l_p.view(-1, 1, 3), U.small_matmul(btb_inv, b.permute(0, 2, 1)))        # [P,1,4]
+            rhs_tail = rhs_1[:, :, -3:]
+            temp = U.small_matmul(rhs_tail, -v_cross).view(-1, 3).detach()
+            cot_f = (-rhs_1[:, :, 0]).reshape(f2.shape).detach()
+        outs, cots = [f2, d2], [cot_f, temp]
         if v_live.requires_grad:                      # d/dv of [v]x (d - c): network.py:798-809
             dc_cross = cross_matrix(d2.detach() - c_live.detach().view(1, 3))
-            outs.append(v_live); cots.append(U.small_matmul(rhs_1[:, :, -3:], dc_cross).view(-1, 3).detach())
+            outs.append(v_live); cots.append(U.small_matmul(rhs_tail, dc_cross).view(-1, 3).detach())
         if c_live.requires_grad:                      # network.py:811-813
             outs.append(c_live); cots.append((-temp.sum(0)).detach())
         lw = getattr(self.dataset, 'learnable_weights', None)

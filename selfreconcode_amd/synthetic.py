@@ -165,6 +165,13 @@ class SyntheticSequence:
                               'cam2world_coord_quat': torch.tensor([0., 0., 1., 0.], device=dev),   # R = diag(-1, 1, -1)
                               'world2cam_coord_trans': torch.tensor([0., 0.15, 2.4], device=dev)}
         self.video_segmented_index = []
+        self._R_cache = None
+
+    def opt_camera_params(self, conf):
+        """dataset/dataset.py:64-74: which camera parameters are optimised (a bool for all, or train.opt_camera of the config)."""
+        names = {'focal_length': 'focal_length', 'princeple_points': 'princeple_points', 'cam2world_coord_quat': 'quat', 'world2cam_coord_trans': 'T'}
+        for key, cname in names.items():
+            self.camera_params[key].requires_grad_(bool(conf) if isinstance(conf, bool) else conf.get_bool(cname))
 
     def learnable_weights(self):
         ws = [c for c in self.conds if c.requires_grad]
@@ -173,15 +180,25 @@ class SyntheticSequence:
         return ws
 
     def get_grad_parameters(self, idxs, device=None):
-        return self.poses[idxs], self.trans[idxs], self.conds[0][idxs], self.conds[1][idxs]
+        """dataset/dataset.py:117-122 (rows of the per-frame tables; index_select: its backward is one index_add)."""
+        idxs = idxs.view(-1)
+        return (torch.index_select(self.poses, 0, idxs), torch.index_select(self.trans, 0, idxs), torch.index_select(self.conds[0], 0, idxs),
+                torch.index_select(self.conds[1], 0, idxs))
 
     def get_camera_parameters(self, N, device=None):
+        """dataset/dataset.py:125-127.  The rotation of a quaternion that is not optimised (config.conf:13) is built once."""
         q = self.camera_params['cam2world_coord_quat'].view(1, 4)
-        q = q / q.norm(p=2, dim=1, keepdim=True)
-        w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
-        R = torch.stack([w * w + x * x - y * y - z * z, 2 * x * y - 2 * w * z, 2 * w * y + 2 * x * z,
-                         2 * w * z + 2 * x * y, w * w - x * x + y * y - z * z, 2 * y * z - 2 * w * x,
-                         2 * x * z - 2 * w * y, 2 * w * x + 2 * y * z, w * w - x * x - y * y + z * z], dim=1).view(1, 3, 3)
+        key = (q.data_ptr(), q._version)
+        if not q.requires_grad and self._R_cache is not None and self._R_cache[0] == key:
+            R = self._R_cache[1]
+        else:
+            q = q / q.norm(p=2, dim=1, keepdim=True)
+            w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+            R = torch.stack([w * w + x * x - y * y - z * z, 2 * x * y - 2 * w * z, 2 * w * y + 2 * x * z,
+                             2 * w * z + 2 * x * y, w * w - x * x + y * y - z * z, 2 * y * z - 2 * w * x,
+                             2 * x * z - 2 * w * y, 2 * w * x + 2 * y * z, w * w - x * x - y * y + z * z], dim=1).view(1, 3, 3)
+            if not q.requires_grad:
+                self._R_cache = (key, R)
         return (self.camera_params['focal_length'].view(1, 2).expand(N, 2), self.camera_params['princeple_points'].view(1, 2).expand(N, 2),
                 R.expand(N, 3, 3), self.camera_params['world2cam_coord_trans'].view(1, 3).expand(N, 3), self.H, self.W)
 
@@ -231,13 +248,14 @@ class SyntheticSequence:
             return {'img': torch.rand((N, H, W, 3), device=dev, generator=g) * 2 - 1, 'mask': self._masks[frame_ids].float(),
                     'normal': torch.rand((N, H, W, 3), device=dev, generator=g) * 2 - 1}
         ys, xs = torch.meshgrid(torch.arange(H, device=dev).float(), torch.arange(W, device=dev).float(), indexing='ij')
-        f = float(self.camera_params['focal_length'][0]); cx = float(self.camera_params['princeple_points'][0]); cy = float(self.camera_params['princeple_points'][1])
-        Tz = float(self.camera_params['world2cam_coord_trans'][2])
+        cp = {k: v.detach() for k, v in self.camera_params.items()}
+        f = float(cp['focal_length'][0]); cx = float(cp['princeple_points'][0]); cy = float(cp['princeple_points'][1])
+        Tz = float(cp['world2cam_coord_trans'][2])
         masks = []
         for i in range(N):
             tr = self.trans[int(frame_ids[i])].detach()
             ux = cx + f * float(tr[0]) / Tz
-            uy = cy - f * (float(tr[1]) + float(self.camera_params['world2cam_coord_trans'][1])) / Tz
+            uy = cy - f * (float(tr[1]) + float(cp['world2cam_coord_trans'][1])) / Tz
             rx, ry = f * 0.56 / Tz, f * 0.63 / Tz
             masks.append((((xs - ux) / rx) ** 2 + ((ys - uy) / ry) ** 2 < 1.0).float())
         return {'img': torch.rand((N, H, W, 3), device=dev, generator=g) * 2 - 1, 'mask': torch.stack(masks),
@@ -254,7 +272,7 @@ STAGE_RESOLUTIONS = {'coarse': COARSE_RESOLUTIONS, 'medium': MEDIUM_RESOLUTIONS,
 
 
 def build_synthetic_scene(device="cuda:0", frame_num=64, H=540, W=540, stage="coarse", resolutions=None, lbs_volume_shape=(65, 225, 129),
-                          conf=None, seed=0, consistent_masks=True):
+                          conf=None, seed=0, consistent_masks=True, opt_camera="config"):
     """SDF (near-sphere geometric init), deformer (MLPTranslator + LBS on a synthetic weight volume), render net,
     Seg3dLossless engine, orchestrator and dataset, wired like model/network.py::getOptNet (:828-909)."""
     from .config import default_config
@@ -281,6 +299,8 @@ def build_synthetic_scene(device="cuda:0", frame_num=64, H=540, W=540, stage="co
     net.remesh_intersect = conf.get_int(f'train.{stage}.point_render.remesh_intersect')
     net.point_radius = conf.get_float(f'train.{stage}.point_render.radius')
     ds = SyntheticSequence(frame_num, H, W, device, seed)
+    # train.py:86 -> dataset.opt_camera_params: the shipped configuration optimises focal length, principal point and T (config.conf:10-15)
+    ds.opt_camera_params(conf.get_config('train.opt_camera') if opt_camera == "config" else opt_camera)
     net.dataset = ds
     net.dctnull = DCTNullSpace(10, 30).to(device)
     if consistent_masks:

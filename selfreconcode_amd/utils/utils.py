@@ -5,6 +5,7 @@ from torch.autograd import Function
 
 from ..ext.FastMinv import Fast3x3Minv, Fast3x3Minv_backward
 from ..mlp_engine import input_grads_only
+from .. import step_ops
 
 
 class FastDiff3x3MinvFunction(Function):
@@ -101,7 +102,9 @@ def sample_points(pc_input, global_sigma, local_sigma, ratio=6):
     return sample_local
 
 
-SINGULAR_COUNT = {}   # device scalars: singular deformation Jacobians seen by the last calls (read them to sync)
+SINGULAR_COUNT = {}   # 'rays' / 'normals' -> bool mask [P] of the rows whose deformation Jacobian was INVERTIBLE in the last call: the
+                      # reference tests it on the host and prints a warning (utils.py:145-150,162-167: one sync per call); here the
+                      # fallback is selected on the device and `(~mask).sum()` is left to whoever wants the count
 
 
 def compute_Jacobian(ps, ds, retain_graph, create_graph, allow_unused=False):
@@ -152,11 +155,12 @@ def compute_deformed_normals(sdf, deformer, ps, defconds, batch_inds, ratio, pha
         ds, grad_d_p = cache['ds'].detach(), cache['J'].detach()
     else:
         ds, grad_d_p = deformed_points_and_jacobian(deformer, ps, defconds, batch_inds, ratio, check)
+    if step_ops.ENABLED and not check and grad_d_p.is_cuda:      # 'test' phase: one kernel, no graph
+        return step_ops.deformed_normals(grad_d_p, onx), ds
     grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
     nx = small_matvec(grad_d_p_inv.transpose(-2, -1), onx.view(-1, 3))
-    # singular Jacobians fall back to J n (reference :145-150).  The reference tests the mask on the host and prints a warning
-    # (one sync per call); here the selection is a device-side where() and the count is left in SINGULAR_COUNT for whoever asks.
-    SINGULAR_COUNT['normals'] = (~inv_mask).sum()
+    # singular Jacobians fall back to J n (reference :145-150), selected on the device
+    SINGULAR_COUNT['normals'] = inv_mask
     nx = torch.where(inv_mask[:, None], nx, small_matvec(grad_d_p, onx.view(-1, 3)))
     nx = nx / nx.norm(dim=1, keepdim=True)
     return nx, ds
@@ -172,9 +176,13 @@ def compute_cardinal_rays(deformer, ps, rays, defconds, batch_inds, ratio, phase
         ds, grad_d_p = deformed_points_and_jacobian(deformer, ps, defconds, batch_inds, ratio, check)
         if cache is not None:
             cache['ds'], cache['J'] = ds, grad_d_p
+    if step_ops.ENABLED and grad_d_p.is_cuda:
+        crays, inv_mask = step_ops.CardinalRays.apply(grad_d_p, rays.view(-1, 3))
+        SINGULAR_COUNT['rays'] = inv_mask
+        return crays, ds
     grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
     crays = small_matvec(grad_d_p_inv, rays.view(-1, 3))
-    SINGULAR_COUNT['rays'] = (~inv_mask).sum()          # (reference :162-167: host test + print; see compute_deformed_normals)
+    SINGULAR_COUNT['rays'] = inv_mask                    # (reference :162-167: host test + print)
     crays = torch.where(inv_mask[:, None], crays, rays.detach())
     crays = crays / crays.norm(dim=1, keepdim=True)
     return crays, ds

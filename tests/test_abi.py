@@ -53,3 +53,27 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "/root/reference" in txt:
                     bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_ctypes_structs_have_the_size_the_header_declares(tmp_path):
+    """Every argument struct crosses the boundary by pointer: the ctypes mirror in _lib.py and the C declaration must agree
+    (gcc compiles the header as plain C -- it has to stay a C header -- and prints sizeof for each)."""
+    import subprocess
+    from selfreconcode_amd import _lib
+    pairs = {"sr_tensor5": _lib.SrTensor5, "sr_gemm_args": _lib.SrGemmArgs, "sr_gemm_tn_args": _lib.SrGemmTnArgs, "sr_lbs_args": _lib.SrLbsArgs,
+             "sr_newton_args": _lib.SrNewtonArgs, "sr_newton2_args": _lib.SrNewton2Args, "sr_chain_args": _lib.SrChainArgs,
+             "sr_refine_args": _lib.SrRefineArgs, "sr_pack_layer": _lib.SrPackLayer, "sr_pack_table": _lib.SrPackTable,
+             "sr_unpack_layer": _lib.SrUnpackLayer, "sr_unpack_table": _lib.SrUnpackTable, "sr_camera": _lib.SrCamera,
+             "sr_ray_pixels": _lib.SrRayPixels}
+    txt = open(os.path.join(ROOT, "include", "selfrecon_hip.h")).read()
+    declared = set(re.findall(r"\}\s*(sr_\w+);", txt))
+    assert declared == set(pairs), declared ^ set(pairs)
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "selfrecon_hip.h"\nint main(void){\n'
+                   + "".join(f'printf("{n} %zu\\n", sizeof({n}));\n' for n in pairs) + "return 0;}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    sizes = dict(line.split() for line in out.strip().splitlines())
+    for n, cls in pairs.items():
+        assert int(sizes[n]) == ctypes.sizeof(cls), (n, sizes[n], ctypes.sizeof(cls))

@@ -35,9 +35,10 @@ def _oracle_scene(net, ds):
     sk = dict(ws=skin.ws.detach().cpu().contiguous(), b_min=skin.b_min.cpu().view(3), b_max=skin.b_max.cpu().view(3), Js=skin.Js.cpu(),
               init_pose=skin.init_pose.cpu())
     leaf = lambda t: t.detach().cpu().clone().requires_grad_(True)
-    q = ds.camera_params['cam2world_coord_quat'].cpu().view(1, 4)
-    cam = dict(focal=ds.camera_params['focal_length'].cpu(), princ=ds.camera_params['princeple_points'].cpu(), R=orc.quat2mat(q)[0],
-               T=ds.camera_params['world2cam_coord_trans'].cpu(), H=H, W=W)
+    q = ds.camera_params['cam2world_coord_quat'].detach().cpu().view(1, 4)
+    camleaf = lambda t: t.detach().cpu().clone().requires_grad_(t.requires_grad)      # the intrinsics / T are optimised (config.conf:10-15)
+    cam = dict(focal=camleaf(ds.camera_params['focal_length']), princ=camleaf(ds.camera_params['princeple_points']), R=orc.quat2mat(q)[0],
+               T=camleaf(ds.camera_params['world2cam_coord_trans']), H=H, W=W)
     tr_sd = {k: v for k, v in net.deformer.defs[0].state_dict().items()}
     return ito.Scene(cp(net.sdf.state_dict()), cp(tr_sd), cp(net.netRender.state_dict()), sk, leaf(ds.poses), leaf(ds.trans), leaf(ds.conds[0]),
                      leaf(ds.conds[1]), cam, net.conf, net.point_radius, net.angThred)
@@ -160,6 +161,11 @@ def test_whole_iteration_with_injected_randoms_vs_oracle():
                 close(p.grad, sd[n].grad, 2e-3, 3e-3, tag + " " + n)
         close(ds.poses.grad, sc.poses.grad, 2e-3, 3e-3, "poses"); close(ds.trans.grad[fids], sc.trans.grad[fo], 2e-3, 3e-3, "trans")
         close(ds.conds[0].grad[fids], sc.dcond.grad[fo], 2e-3, 3e-3, "d_cond")
+        # camera: focal length, principal point and T are learnable in the shipped configuration (config.conf:10-15); their gradients come
+        # from the silhouette projection (inner backward), the per-pixel rays (colour branch) and the implicit differentiation (:798-813)
+        for key, okey in (('focal_length', 'focal'), ('princeple_points', 'princ'), ('world2cam_coord_trans', 'T')):
+            assert ds.camera_params[key].requires_grad and ds.camera_params[key].grad is not None, key
+            close(ds.camera_params[key].grad, sc.cam[okey].grad, 3e-3, 3e-3, "camera " + key)
         assert ds.conds[1].grad is None or float(ds.conds[1].grad.abs().max()) == 0.0     # rendcond[batch_inds] is passed and ignored (utils.py:171-172)
     finally:
         mlp_engine.set_deferred_param_grads(False)
