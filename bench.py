@@ -132,7 +132,7 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
     if gemm_events:
         net.forward_time = (-(steps // 2)) % Rm or Rm
         net.remesh_events, net.refiner_events = [], []
-        mlp_engine.PROFILE.reset(enabled=True, reserve=900 * steps)
+        mlp_engine.PROFILE.reset(enabled=True, reserve=1100 * steps)
         el_i, _, _ = timed(steps)
         prof = mlp_engine.PROFILE.summary()
         shapes = mlp_engine.PROFILE.by_shape()
@@ -214,7 +214,7 @@ def main():
     if rank != 0:
         return
     FR, RAYS = STAGES[args.stage]["frames"], STAGES[args.stage]["rays"]
-    flops_step = prof.get("flops_total", 0.0) / max(args.steps, 1)
+    flops_step = (prof.get("flops_total", 0.0) + prof.get("flops_total_tn", 0.0)) / max(args.steps, 1)      # every layer GEMM: forward, backward-data, weight-gradient, refiner chains
     out = {
         "metric": f"train.py-equivalent iterations/sec (540x540, {RAYS} rays/frame x {FR} frame{'s' if FR > 1 else ''} per GPU)",
         "value": round(args.steps * world / elapsed, 4), "unit": "iterations/s",
@@ -246,6 +246,10 @@ def main():
                      "achieved_launches_ge_64k_rows": prof.get("tflops_large"), "launches_ge_64k_rows": prof.get("launches_large"),
                      "whole_step_tflops": round(flops_step / (main_rec["ms_per_step"] * 1e-3) / 1e12, 3) if flops_step else None,
                      "whole_step_frac": round(flops_step / (main_rec["ms_per_step"] * 1e-3) / 1e12 / 157.3, 4) if flops_step else None,
+                     "weight_gradient_gemm": {"kernel": "gemm_tn_kernel + slab_reduce_kernel (dW = Z^T A over the rows, deterministic slab reduction)",
+                                              "achieved": prof.get("tflops_tn"), "launches": prof.get("launches_tn"), "avg_launch_us": prof.get("avg_us_tn"),
+                                              "frac": round((prof.get("tflops_tn") or 0.0) / 157.3, 4)},
+                     "flop_per_step": {"nt_and_chains": round(prof.get("flops_total", 0.0) / max(args.steps, 1)), "weight_gradient": round(prof.get("flops_total_tn", 0.0) / max(args.steps, 1))},
                      "note": "event pairs are recorded in a SECOND pass over the same K steps (ms_per_step_instrumented); the headline pass carries no events",
                      "traffic": None},
     }

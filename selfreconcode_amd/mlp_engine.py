@@ -113,14 +113,19 @@ class _GemmProfile:
             n = sum(1 for k in sel if k)
             return (f / (ms * 1e-3) / 1e12 if ms > 0 else 0.0), n, (ms * 1e3 / n if n else 0.0), (f / n if n else 0.0)
 
-        alone = [not r[4] for r in self.records]
+        nt = [r[5][2] != "tn" for r in self.records]                  # the NT tile code (forward / backward-data GEMMs, refiner chains)
+        alone = [k and not r[4] for k, r in zip(nt, self.records)]
         tf, n, us, fl = rate(alone)                                   # launches that had the GPU to themselves
-        tf_all, n_all, us_all, _ = rate([True] * len(self.records))
+        tf_all, n_all, us_all, _ = rate(nt)
         tf_big, n_big, _, _ = rate([a and r[3] >= 65536 for a, r in zip(alone, self.records)])
+        tf_tn, n_tn, us_tn, _ = rate([not k for k in nt])             # the weight-gradient (TN) kernel + slab reduction
         self._times = times
+        f_nt = float(sum(r[2] for r, k in zip(self.records, nt) if k))
+        f_tn = float(sum(r[2] for r, k in zip(self.records, nt) if not k))
         return {"tflops": round(tf, 3), "launches": n, "avg_us": round(us, 3), "avg_flop": round(fl, 1), "tflops_large": round(tf_big, 3),
                 "launches_large": n_big, "tflops_all": round(tf_all, 3), "launches_all": n_all, "avg_us_all": round(us_all, 3),
-                "avg_flop_all": round(sum(r[2] for r in self.records) / max(n_all, 1), 1), "flops_total": float(sum(r[2] for r in self.records))}
+                "avg_flop_all": round(f_nt / max(n_all, 1), 1), "flops_total": f_nt, "flops_total_tn": f_tn,
+                "tflops_tn": round(tf_tn, 3), "launches_tn": n_tn, "avg_us_tn": round(us_tn, 3)}
 
     def by_shape(self):
         """Per (M, N, K, epilogue mode, overlap flag): launches, total FLOP, total event time, TFLOP/s -- the table that makes
@@ -173,6 +178,13 @@ def _gemm_tn(Z, ldz, A, lda, R, N, K, lddw, group=1, dW=None, db=None, accumulat
     a.Z, a.ldz, a.A, a.lda, a.dW, a.lddw, a.partial = _lib.ptr(Z), ldz, _lib.ptr(A), lda, _lib.ptr(dW), lddw, _lib.ptr(partial)
     a.R, a.N, a.K, a.splits, a.accumulate = R, N, K, splits.value, 1 if accumulate else 0
     a.db, a.db_partial, a.group = _lib.ptr(db), _lib.ptr(partial) + 4 * max(int(ws), 1), group
+    if PROFILE.enabled and R >= 128 and N > 32:        # weight-gradient GEMM + its slab reduction, as one interval
+        e0, e1 = PROFILE.pair()
+        e0.record()
+        _lib.call("sr_mlp_gemm_tn", ctypes.byref(a), _lib.stream_of(Z))
+        e1.record()
+        PROFILE.records.append((e0, e1, 2.0 * R * N * K, R, PROFILE.overlap, (N, K, "tn", group)))
+        return dW, db
     _lib.call("sr_mlp_gemm_tn", ctypes.byref(a), _lib.stream_of(Z))
     return dW, db
 

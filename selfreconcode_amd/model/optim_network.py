@@ -190,13 +190,17 @@ class OptimNetwork(nn.Module):
         return out
 
     # ------------------------------------------------------------------ rasterisation stand-ins
-    def _side_stream(self, device):
+    def _side_stream(self, device, which=0):
         st = getattr(self, "_side_streams", None)
         if st is None:
             st = self._side_streams = {}
-        key = str(device)
+        key = (str(device), which)
         if key not in st:
-            st[key] = torch.cuda.Stream(device=device)
+            # high priority: the ray selection on this stream is a handful of tiny kernels with a host round trip after each
+            # (nonzero); at equal priority each of them queues behind the template branch's thousands of GEMM workgroups and the
+            # refiner that follows is not even issued before that branch has drained
+            prio = int(__import__('os').environ.get('SR_SIDE_STREAM_PRIORITY', '-1'))
+            st[key] = torch.cuda.Stream(device=device, priority=prio)
         return st[key]
 
     def _seed_rays(self, defTmpVs, cameras, H, W, canonical=None):
@@ -311,15 +315,6 @@ class OptimNetwork(nn.Module):
             pixels = torch.stack([col_inds, row_inds, torch.ones_like(col_inds)], dim=-1).float()
             rays = cameras.view_rays(pixels)
             initTmpPs = initTmpPs.contiguous()
-            # vertex subsets of the eikonal / def-regu samples: the Bernoulli masks do not depend on the vertex positions, so their
-            # index lists (one host sync each) are made here; the gathers happen after the template step, as in the reference
-            vsel = rand['vert_select'][:TmpVnum] if 'vert_select' in rand else torch.rand(TmpVnum, device=device)
-            eik_idx = (vsel < 4096. / float(TmpVnum)).nonzero(as_tuple=False).view(-1)
-            use_regu = 'def_regu' in self.conf and self.conf.get_float('def_regu.weight') > 0.
-            regu_idx = None
-            if use_regu:
-                vsel2 = rand['vert_select2'][:TmpVnum] if 'vert_select2' in rand else torch.rand(TmpVnum, device=device)
-                regu_idx = (vsel2 < 4096. / float(TmpVnum)).nonzero(as_tuple=False).view(-1)
             if debug is not None:
                 debug.update(batch_inds=batch_inds, row_inds=row_inds, col_inds=col_inds, seeds=initTmpPs.clone())
             selected = torch.cuda.Event()
@@ -348,6 +343,21 @@ class OptimNetwork(nn.Module):
                 r1.record(rstream); rev.append((r0, r1))
             refined = torch.cuda.Event()
             refined.record(rstream)
+        aux = self._side_stream(device, 1)
+        with torch.cuda.stream(aux), torch.no_grad():
+            # vertex subsets of the eikonal / def-regu samples: the Bernoulli masks do not depend on the vertex positions, so their
+            # index lists (one host sync each) are made on a stream of their own AFTER the refiner has been issued -- nothing
+            # before the refiner waits for them, and they do not wait for the refiner; the gathers happen after the template step,
+            # as in the reference
+            aux.wait_event(fork)
+            vsel = rand['vert_select'][:TmpVnum] if 'vert_select' in rand else torch.rand(TmpVnum, device=device)
+            eik_idx = (vsel < 4096. / float(TmpVnum)).nonzero(as_tuple=False).view(-1)
+            use_regu = 'def_regu' in self.conf and self.conf.get_float('def_regu.weight') > 0.
+            regu_idx = None
+            if use_regu:
+                vsel2 = rand['vert_select2'][:TmpVnum] if 'vert_select2' in rand else torch.rand(TmpVnum, device=device)
+                regu_idx = (vsel2 < 4096. / float(TmpVnum)).nonzero(as_tuple=False).view(-1)
+        main.wait_stream(aux)
         main.wait_stream(side)
         mlp_engine.PROFILE.overlap = False
         for t in (batch_inds, row_inds, col_inds, initTmpPs, rays, eik_idx, regu_idx, pixels, check):

@@ -1,4 +1,4 @@
-"""GPU idle-gap analysis of a rocprofv3 --kernel-trace CSV: python tools/gap_analysis.py <output dir>.
+"""GPU idle-gap analysis of a rocprofv3 --kernel-trace CSV: python tools/gap_analysis.py <output dir> [first_iteration last_iteration+1].
 Reports busy / idle time and which kernel transitions the idle time sits between (host-side launch cost, syncs)."""
 import csv, sys, glob, collections
 f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
@@ -6,9 +6,22 @@ rows = []
 for r in csv.DictReader(open(f)):
     rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
 rows.sort()
-# keep the last 60% (steady state)
-n0 = int(len(rows) * 0.4)
-rows = rows[n0:]
+if len(sys.argv) > 3:
+    # window of whole iterations [A, B) counted in Adam steps (multi_tensor_apply bursts of >= 4 kernels): e.g. the clean pass of bench.py
+    A, B = int(sys.argv[2]), int(sys.argv[3])
+    bursts = []
+    for s, e, n in rows:
+        if 'multi_tensor_apply' in n:
+            if not bursts or s - bursts[-1][-1] > 2_000_000: bursts.append([s])
+            else: bursts[-1].append(s)
+    ends = [b[-1] for b in bursts if len(b) >= 4]
+    t0, t1 = ends[A - 1], ends[B - 1]
+    rows = [r for r in rows if t0 < r[0] <= t1 + 100_000]
+    print(f'window: iterations {A}..{B - 1} of {len(ends)} ({(t1 - t0) / 1e6 / (B - A):.2f} ms / iteration under tracing)')
+else:
+    # keep the last 60% (steady state)
+    n0 = int(len(rows) * 0.4)
+    rows = rows[n0:]
 span = rows[-1][1] - rows[0][0]
 busy = 0; gaps = collections.Counter(); gapn = collections.Counter(); end = rows[0][0]
 big = []

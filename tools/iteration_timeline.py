@@ -1,5 +1,5 @@
 """Timeline of ONE training iteration from a rocprofv3 --kernel-trace CSV: python tools/iteration_timeline.py <output dir> [k]
-Iterations are delimited by the optimizer's multi_tensor_apply bursts; the k-th from the end is printed (default 3):
+Iterations are delimited by Adam's multi_tensor_apply bursts; the k-th from the end is printed (default 3):
 segments of continuous GPU activity (any stream) with their busy time, dominant kernels and the idle gap that follows."""
 import csv, sys, glob, collections
 f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
@@ -17,7 +17,7 @@ bursts = []
 for s in opt:
     if not bursts or s - bursts[-1][-1] > 2_000_000: bursts.append([s])
     else: bursts[-1].append(s)
-ends = [b[-1] for b in bursts]
+ends = [b[-1] for b in bursts if len(b) >= 4]          # Adam (several multi-tensor launches); the template SGD step is a 1-2 kernel burst
 assert len(ends) > k + 1, len(ends)
 t0, t1 = ends[-k - 2], ends[-k - 1]
 it = [r for r in rows if t0 < r[0] <= t1 + 200_000]

@@ -5,6 +5,7 @@
                                 FLOP, ms, TFLOP/s -- what `roofline.achieved` is the total of
   <tag>_pmc_gemm_nt.json        HBM bytes per launch of the layer GEMMs (calibrated), next to the algorithmic bytes of the same launches
   <tag>_hbm_kernels.md, <tag>_gemm_bench.txt   micro-benchmarks
+  <tag>_gaps.txt, <tag>_timeline.txt           GPU busy / idle of the traced run and one iteration as segments of GPU activity
 and prints the tables for <tag>_summary.md.
 Counter units (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE count KiB.  The guide's gfx950 rule (double FETCH_SIZE)
 holds for wide coalesced streams; for THIS kernel's operand-tile loads the factor is measured on launches with a known byte count
@@ -21,7 +22,7 @@ prof = line(os.path.join(src, "stats.log"))
 json.dump(prof, open(os.path.join(dst, f"{tag}_profiled_bench.json"), "w"), indent=1)
 stats = max(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)
 shutil.copy(stats, os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
-for name in ("hbm_kernels.md", "gemm_bench.txt"):
+for name in ("hbm_kernels.md", "gemm_bench.txt", "gaps.txt", "timeline.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
 shapes = json.load(open(os.path.join(src, "gemm_shapes.json")))
@@ -43,7 +44,7 @@ for c, idx in (("FETCH_SIZE", 0), ("WRITE_SIZE", 1)):
 def alg_bytes(rows):
     tot, n = 0.0, 0
     for r in rows:
-        if r["mode"] == "chain":
+        if r["mode"] in ("chain", "tn"):
             continue
         M, N, K = r["M"], r["N"], r["K"]
         b = 4.0 * (M * K + N * K + M * N) + (4.0 * M * N if r["mode"] == 1 else 0.0)      # the backward epilogue re-reads the stored activation
@@ -77,7 +78,8 @@ json.dump(out, open(os.path.join(dst, f"{tag}_pmc_gemm_nt.json"), "w"), indent=1
 rows = list(csv.DictReader(open(stats)))
 total = sum(int(r["TotalDurationNs"]) for r in rows)
 calls = sum(int(r["Calls"]) for r in rows)
-iters = prof["steps"] + prof["warmup"] + prof["config"]["optimizer"]["settle_iters_lr_timed"] + prof["config"]["optimizer"]["settle_iters_lr_1e-4"]
+passes = 2 if prof.get("ms_per_step_instrumented") is not None else 1          # bench.py times the K steps twice: clean, then with the event pairs
+iters = prof["steps"] * passes + prof["warmup"] + prof["config"]["optimizer"]["settle_iters_lr_timed"] + prof["config"]["optimizer"]["settle_iters_lr_1e-4"]
 print(f"un-profiled bench: {bench['ms_per_step']:.2f} ms / iteration ({bench['value']:.2f} it/s), converged {bench['config']['rays_converged_frac']:.3f}; "
       f"profiled command: {prof['ms_per_step']:.1f} ms / iteration under tracing, converged {prof['config']['rays_converged_frac']:.3f}, {iters} iterations")
 print(f"GPU kernel time {total / 1e6 / iters:.1f} ms / iteration, {calls / iters:.0f} launches / iteration\n")
@@ -96,15 +98,22 @@ for r in shapes:
         key = ("refiner chain (all layers of both nets)", "-", "-", "-")
     else:
         mb = "M<8k" if r["M"] < 8192 else "M<64k" if r["M"] < 65536 else "M>=64k"
-        key = (mb, r["N"], r["K"], "bwd-data" if r["mode"] == 1 else "fwd")
+        key = (mb, r["N"], r["K"], "weight-grad (TN)" if r["mode"] == "tn" else "bwd-data" if r["mode"] == 1 else "fwd")
     a = agg[key]; a[0] += r["launches"]; a[1] += r["flop"]; a[2] += r["ms"]
 steps = bench["steps"]
 print("\n| class | N | K | epilogue | launches / it | ms / it | TFLOP/s |\n|---|---|---|---|---|---|---|")
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:18]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:24]:
     print(f"| {k[0]} | {k[1]} | {k[2]} | {k[3]} | {v[0] / steps:.1f} | {v[2] / steps:.2f} | {v[1] / v[2] / 1e9:.1f} |")
-tf = sum(v[1] for v in agg.values()); tm = sum(v[2] for v in agg.values())
-print(f"\nall recorded launches: {tf / steps / 1e12:.3f} TFLOP / iteration in {tm / steps:.2f} ms of event time -> {tf / tm / 1e9:.1f} TFLOP/s "
-      f"({tf / tm / 1e9 / 157.3:.3f} of 157.3); whole step: {tf / steps / 1e12:.3f} TFLOP / {bench['ms_per_step']:.2f} ms = {tf / steps / bench['ms_per_step'] / 1e9:.1f} TFLOP/s")
+nt = {k: v for k, v in agg.items() if k[3] != "weight-grad (TN)"}; tn = {k: v for k, v in agg.items() if k[3] == "weight-grad (TN)"}
+tf = sum(v[1] for v in nt.values()); tm = sum(v[2] for v in nt.values())
+tf2 = sum(v[1] for v in tn.values()); tm2 = sum(v[2] for v in tn.values())
+print(f"\nNT tile code (forward, backward-data, refiner chains), all recorded launches: {tf / steps / 1e12:.3f} TFLOP / iteration in {tm / steps:.2f} ms of event "
+      f"time -> {tf / tm / 1e9:.1f} TFLOP/s ({tf / tm / 1e9 / 157.3:.3f} of 157.3)")
+if tm2 > 0:
+    print(f"weight-gradient kernel (TN + slab reduction): {tf2 / steps / 1e12:.3f} TFLOP / iteration in {tm2 / steps:.2f} ms -> {tf2 / tm2 / 1e9:.1f} TFLOP/s "
+          f"({tf2 / tm2 / 1e9 / 157.3:.3f} of 157.3)")
+print(f"whole step: {(tf + tf2) / steps / 1e12:.3f} TFLOP / {bench['ms_per_step']:.2f} ms = {(tf + tf2) / steps / bench['ms_per_step'] / 1e9:.1f} TFLOP/s "
+      f"({(tf + tf2) / steps / bench['ms_per_step'] / 1e9 / 157.3:.3f} of 157.3)")
 print("\nroofline:", json.dumps(bench["roofline"]))
 print("cpu_baseline:", json.dumps(bench["cpu_baseline"]))
 print("pmc:", json.dumps(out["gemm_nt_wide"]), json.dumps(out["calibration"]))
