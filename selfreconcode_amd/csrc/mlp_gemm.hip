@@ -477,26 +477,36 @@ __global__ __launch_bounds__(ChainCfg::kThreads) __attribute__((amdgpu_waves_per
 // ------------------------------------------------------------------------------------------------
 // dW[N,K] = sum_r Z[r,N]^T A[r,K]   (split over r into `splits` slabs, reduced below)
 constexpr int TBR = 32;          // rows (reduction) per tile step
-constexpr int TLD = 128 + 4;     // LDS pitch for the [TBR][128] images
-constexpr int TN_LDS_FLOATS = 4 * TBR * TLD;   // Z and A images, double buffered (67.6 KB, dynamic)
+// Tile of dW: ZW columns of Z (rows of dW) x XW columns of A (columns of dW); 4 waves of 64 x 64 each.  128 x 128 is the general
+// shape; 256 x 64 serves the first layers (K = 39: on the square tile 70 % of the A columns were clamped re-reads).
+template <int ZW, int XW>
+struct TnCfg {
+  static constexpr int ZLD = ZW + 4, XLD = XW + 4;                       // LDS pitches of the [TBR][width] images
+  static constexpr int kZ = TBR * ZLD, kX = TBR * XLD;
+  static constexpr int kLdsFloats = 2 * (kZ + kX);                        // both images double buffered (dynamic LDS)
+  static constexpr int TLZ = TBR * (ZW / 4) / 256, TLX = TBR * (XW / 4) / 256;   // float4 loads per thread and step
+  static constexpr int WN = XW / 64;                                      // waves along the A columns
+};
 
+template <int ZW, int XW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_tn_kernel(sr_gemm_tn_args g, int rows_per_split) {
+  using C = TnCfg<ZW, XW>;
   extern __shared__ __attribute__((aligned(16))) float tn_smem[];
-  auto Zs = [&](int buf) -> float* { return tn_smem + buf * (TBR * TLD); };
-  auto Xs = [&](int buf) -> float* { return tn_smem + (2 + buf) * (TBR * TLD); };
-  const int tiles_k = (g.K + 127) / 128;
-  const int tiles_n = (g.N + 127) / 128;
+  auto Zs = [&](int buf) -> float* { return tn_smem + buf * C::kZ; };
+  auto Xs = [&](int buf) -> float* { return tn_smem + 2 * C::kZ + buf * C::kX; };
+  const int tiles_k = (g.K + XW - 1) / XW;
+  const int tiles_n = (g.N + ZW - 1) / ZW;
   // XCD-aware order: workgroup b runs on XCD b % 8 with a private L2.  The tiles of one row-slice (split) all read the
   // same Z and A rows, so give each XCD whole splits: virtual id = xcd * (grid/8) + b / 8.  (Before: the 4 k-tiles /
   // 4 n-tiles of a slice sat on different XCDs and every operand row was streamed from HBM 4 times.)
   int vb = blockIdx.x;
   if ((gridDim.x & 7) == 0) vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int tile = vb % (tiles_k * tiles_n), split = vb / (tiles_k * tiles_n);
-  const int n0 = (tile / tiles_k) * 128, k0 = (tile % tiles_k) * 128;
+  const int n0 = (tile / tiles_k) * ZW, k0 = (tile % tiles_k) * XW;
   const int r_begin = split * rows_per_split;
   const int r_end = min(g.R, r_begin + rows_per_split);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kh = lane >> 5;
+  const int wm = wave / C::WN, wn = wave % C::WN, li = lane & 31, kh = lane >> 5;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -506,22 +516,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // A step moves a [TBR rows][128 cols] tile of Z and of A: TBR*32 float4 each, TLOADS per thread and operand.  Like the NT
+  // A step moves a [TBR rows][ZW cols] tile of Z and a [TBR][XW] tile of A: TLZ / TLX float4 per thread.  Like the NT
   // loop it is branch-free (one basic block): row addresses are clamped into the slice, rows past its end are zeroed with
   // selects when the registers go to LDS (they are the reduction dimension and must contribute nothing), and columns past
   // N / K are clamped re-reads whose products land in rows / columns of dW that are never stored.
-  constexpr int TLOADS = TBR * 32 / 256;
-  const int cq4 = (threadIdx.x & 31) * 4, lrow = threadIdx.x >> 5;    // this thread's column quad and first row inside a tile
+  constexpr int TLZ = C::TLZ, TLX = C::TLX;
+  constexpr int ZT = ZW / 4, XT = XW / 4;                                   // threads per image row
+  const int cqz = (threadIdx.x % ZT) * 4, lrz = threadIdx.x / ZT;          // this thread's column quad and first row inside a tile
+  const int cqx = (threadIdx.x % XT) * 4, lrx = threadIdx.x / XT;
   const int zmax = ((g.N + 3) & ~3) - 4, xmax = ((g.K + 3) & ~3) - 4;
-  const float* zcol = g.Z + (n0 + cq4 < zmax ? n0 + cq4 : zmax);
-  const float* xcol = g.A + (k0 + cq4 < xmax ? k0 + cq4 : xmax);
-  f32x4 rz[TLOADS], rx[TLOADS];
+  const float* zcol = g.Z + (n0 + cqz < zmax ? n0 + cqz : zmax);
+  const float* xcol = g.A + (k0 + cqx < xmax ? k0 + cqx : xmax);
+  f32x4 rz[TLZ], rx[TLX];
   auto load = [&](int r0) {
 #pragma unroll
-    for (int j = 0; j < TLOADS; ++j) {
-      int gr = r0 + lrow + j * 8;
+    for (int j = 0; j < TLZ; ++j) {
+      int gr = r0 + lrz + j * (256 / ZT);
       gr = gr < r_end ? gr : r_end - 1;
       rz[j] = *reinterpret_cast<const f32x4*>(zcol + (int64_t)gr * g.ldz);
+    }
+#pragma unroll
+    for (int j = 0; j < TLX; ++j) {
+      int gr = r0 + lrx + j * (256 / XT);
+      gr = gr < r_end ? gr : r_end - 1;
       rx[j] = *reinterpret_cast<const f32x4*>(xcol + (int64_t)gr * g.lda);
     }
   };
@@ -529,26 +546,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     float* zs = Zs(buf);
     float* xs = Xs(buf);
 #pragma unroll
-    for (int j = 0; j < TLOADS; ++j) {
-      const int row = lrow + j * 8;
+    for (int j = 0; j < TLZ; ++j) {
+      const int row = lrz + j * (256 / ZT);
       const bool ok = r0 + row < r_end;
-      f32x4 z = rz[j], x = rx[j];
+      f32x4 z = rz[j];
       z.x = ok ? z.x : 0.f; z.y = ok ? z.y : 0.f; z.z = ok ? z.z : 0.f; z.w = ok ? z.w : 0.f;
+      *reinterpret_cast<f32x4*>(zs + row * C::ZLD + cqz) = z;
+    }
+#pragma unroll
+    for (int j = 0; j < TLX; ++j) {
+      const int row = lrx + j * (256 / XT);
+      const bool ok = r0 + row < r_end;
+      f32x4 x = rx[j];
       x.x = ok ? x.x : 0.f; x.y = ok ? x.y : 0.f; x.z = ok ? x.z : 0.f; x.w = ok ? x.w : 0.f;
-      *reinterpret_cast<f32x4*>(zs + row * TLD + cq4) = z;
-      *reinterpret_cast<f32x4*>(xs + row * TLD + cq4) = x;
+      *reinterpret_cast<f32x4*>(xs + row * C::XLD + cqx) = x;
     }
   };
 
   // fragments of 8 k-steps (16 rows): one dword per k-step and 32-wide block
   constexpr int HS = TBR / 4;   // k-steps per half tile
   float z0a[HS], z1a[HS], x0a[HS], x1a[HS], z0b[HS], z1b[HS], x0b[HS], x1b[HS];
-  const int zoff = kh * TLD + wm * 64 + li, xoff = kh * TLD + wn * 64 + li;
+  const int zoff = kh * C::ZLD + wm * 64 + li, xoff = kh * C::XLD + wn * 64 + li;
   auto read_half = [&](int buf, int half, float (&z0)[HS], float (&z1)[HS], float (&x0)[HS], float (&x1)[HS]) {
-    const float* zb = Zs(buf) + zoff + half * HS * 2 * TLD;
-    const float* xb = Xs(buf) + xoff + half * HS * 2 * TLD;
+    const float* zb = Zs(buf) + zoff + half * HS * 2 * C::ZLD;
+    const float* xb = Xs(buf) + xoff + half * HS * 2 * C::XLD;
 #pragma unroll
-    for (int e = 0; e < HS; ++e) { z0[e] = zb[2 * e * TLD]; z1[e] = zb[2 * e * TLD + 32]; x0[e] = xb[2 * e * TLD]; x1[e] = xb[2 * e * TLD + 32]; }
+    for (int e = 0; e < HS; ++e) { z0[e] = zb[2 * e * C::ZLD]; z1[e] = zb[2 * e * C::ZLD + 32]; x0[e] = xb[2 * e * C::XLD]; x1[e] = xb[2 * e * C::XLD + 32]; }
   };
   auto mfma_half = [&](const float (&z0)[HS], const float (&z1)[HS], const float (&x0)[HS], const float (&x1)[HS]) {
 #pragma unroll
@@ -590,17 +613,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
       read_half(cur, 1, z0b, z1b, x0b, x1b);
       mfma_half(z0a, z1a, x0a, x1a);
 #pragma unroll
-      for (int i = 0; i < 2 * TLOADS; ++i) {
+      for (int i = 0; i < TLZ + TLX; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
 #pragma unroll
-      for (int i = 0; i < 2 * TLOADS; ++i) {
+      for (int i = 0; i < TLZ + TLX; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
 #pragma unroll
-      for (int i = 0; i < 4 * HS - 4 * TLOADS; ++i) {
+      for (int i = 0; i < 4 * HS - 2 * (TLZ + TLX); ++i) {
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
@@ -616,15 +639,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
   }
   __syncthreads();
-  if (do_bias) {   // (block-uniform) waves wn == 0 hold all 128 columns; fold the two row parities
-    float* red = Xs(0);
+  if (do_bias) {   // (block-uniform) waves wn == 0 hold all ZW columns; fold the two row parities
+    float* red = Zs(0);
     if (wn == 0) {
       const bool use = kh == 0 || g.group == 1;
-      red[kh * 128 + wm * 64 + li] = use ? bsum0 : 0.f;
-      red[kh * 128 + wm * 64 + 32 + li] = use ? bsum1 : 0.f;
+      red[kh * ZW + wm * 64 + li] = use ? bsum0 : 0.f;
+      red[kh * ZW + wm * 64 + 32 + li] = use ? bsum1 : 0.f;
     }
     __syncthreads();
-    if (threadIdx.x < 128 && n0 + threadIdx.x < g.N) g.db_partial[(int64_t)split * g.N + n0 + threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 128];
+    if (threadIdx.x < ZW && n0 + threadIdx.x < g.N) g.db_partial[(int64_t)split * g.N + n0 + threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + ZW];
   }
   float* out = g.partial + (int64_t)split * g.N * g.lddw;
 #pragma unroll
@@ -640,6 +663,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
       }
     }
 }
+
+// 256 x 64 tiles when the A operand is at most 64 columns wide and dW has at least 256 rows
+static inline bool tn_narrow(int N, int64_t K) { return K <= 64 && N >= 256; }
 
 // dW = (accumulate ? dW : 0) + sum_s partial[s]; padding columns [K, lddw) are written as 0.  The same launch folds the
 // bias-gradient partials (indices past N * lddw): db = (accumulate ? db : 0) + sum_s db_partial[s].
@@ -809,7 +835,7 @@ int sr_mlp_chain(const sr_chain_args* a, void* stream) {
 }
 
 int64_t sr_mlp_gemm_tn_workspace_floats(int32_t R, int32_t N, int64_t lddw, int32_t* splits_out) {
-  const int tiles = (int)(sr_cdiv(N, 128) * sr_cdiv(lddw, 128));
+  const int tiles = tn_narrow(N, lddw) ? (int)sr_cdiv(N, 256) : (int)(sr_cdiv(N, 128) * sr_cdiv(lddw, 128));
   static const int target = getenv("SR_TN_BLOCKS") ? atoi(getenv("SR_TN_BLOCKS")) : 512;   // tuning switch
   int splits = (int)sr_cdiv(target, tiles);           // two workgroups per CU are resident (LDS): one full wave of the chip; every
                                                       // further slab costs a 64 KB partial tile written and read again
@@ -825,11 +851,20 @@ int sr_mlp_gemm_tn(const sr_gemm_tn_args* a, void* stream) {
   if (a->R > 0 && (!a->Z || !a->A)) return SR_EINVAL;
   if ((a->ldz & 3) || (a->lda & 3) || ((uintptr_t)a->Z & 15) || ((uintptr_t)a->A & 15) || a->lddw < a->K) return SR_EINVAL;
   if ((a->db != nullptr) != (a->db_partial != nullptr) || (a->db && a->group < 1)) return SR_EINVAL;
-  const int tiles = (int)(sr_cdiv(a->N, 128) * sr_cdiv(a->K, 128));
+  const bool narrow = tn_narrow(a->N, a->lddw);        // (the same rule as the workspace query: it sized `splits`)
+  const int tiles = narrow ? (int)sr_cdiv(a->N, 256) : (int)(sr_cdiv(a->N, 128) * sr_cdiv(a->K, 128));
   int rows_per_split = (int)sr_cdiv(a->R, a->splits);
   rows_per_split = (int)(sr_cdiv(rows_per_split, TBR) * TBR);
-  if (a->R > 0)
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * a->splits), dim3(256), TN_LDS_FLOATS * sizeof(float), (hipStream_t)stream, *a, rows_per_split);
+  if (a->R > 0) {
+    using Narrow = TnCfg<256, 64>;
+    using Square = TnCfg<128, 128>;
+    if (narrow)
+      hipLaunchKernelGGL((gemm_tn_kernel<256, 64>), dim3(tiles * a->splits), dim3(256), Narrow::kLdsFloats * sizeof(float), (hipStream_t)stream, *a,
+                         rows_per_split);
+    else
+      hipLaunchKernelGGL((gemm_tn_kernel<128, 128>), dim3(tiles * a->splits), dim3(256), Square::kLdsFloats * sizeof(float), (hipStream_t)stream, *a,
+                         rows_per_split);
+  }
   const int64_t total = (int64_t)a->N * a->lddw + (a->db ? a->N : 0);
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(sr_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, a->partial, a->dW,
                      a->N, a->K, a->lddw, a->R > 0 ? a->splits : 0, a->accumulate, a->db_partial, a->db);

@@ -186,7 +186,8 @@ def test_sdf_only_variant_matches_full_network():
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 3, 7), (63, 33, 39), (64, 32, 40), (65, 64, 33), (129, 257, 167), (300, 473, 512),
-                                   (1000, 167, 289), (4097, 512, 41), (6129, 3, 512), (257, 31, 65), (8192, 130, 96)])
+                                   (1000, 167, 289), (4097, 512, 41), (6129, 3, 512), (257, 31, 65), (8192, 130, 96),
+                                   (5000, 512, 39), (3001, 257, 64), (70001, 300, 7), (1000, 256, 65)])      # + the 256 x 64 weight-gradient tile (K <= 64, N >= 256) and its edges
 def test_gemm_kernels_ragged_shapes_vs_float64(M, N, K):
     """The layer-GEMM kernels on shapes that hit every clamp of the branch-free loaders (row tails, K tails inside and across
     float4s, narrow / ragged N, every tile configuration), with NaN planted in all padding the kernels are allowed to read:

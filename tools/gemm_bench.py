@@ -19,6 +19,9 @@ for M in (262144, 49152, 24576, 6144, 512):
     Z=torch.randn(M,512,device=dev); X=torch.randn(M,512,device=dev)
     ms=timeit(lambda: me._gemm_tn(Z,512,X,512,M,512,512,512,1))
     print(f"TN R={M:7d} 512x512: {ms*1e3:8.1f} us  {2*M*512*512/ms/1e9:7.1f} TF/s", flush=True)
+    X0=torch.randn(M,40,device=dev)                 # first-layer weight gradient: dW [512, 39] (256 x 64 tiles)
+    ms=timeit(lambda: me._gemm_tn(Z,512,X0,40,M,512,39,40,1))
+    print(f"TN R={M:7d} 512x39 : {ms*1e3:8.1f} us  {2*M*512*39/ms/1e9:7.1f} TF/s  {(M*552*4)/ms/1e6:7.1f} GB/s of operand rows", flush=True)
 # vendor library (hipBLASLt / rocBLAS through torch) on the same fp32 shapes: the practical fp32 MFMA ceiling on this part
 torch.backends.cuda.matmul.allow_tf32 = False
 for M in (262144, 49152, 24576, 6144):
