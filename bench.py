@@ -201,6 +201,8 @@ def main():
             net.sdf(x, 1.0)
         torch.cuda.synchronize(); sdf_gs = 5 * x.shape[0] / (time.perf_counter() - s) / 1e9 if x.shape[0] else 0.0
     V = main_rec["template_vertices"]
+    hbm = {"peak_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2), "reserved_gb": round(torch.cuda.memory_reserved(device) / 2 ** 30, 2),
+           "device_allocations": torch.cuda.memory_stats(device).get("num_device_alloc", None)}
     del net
     gc.collect(); torch.cuda.empty_cache()
 
@@ -237,6 +239,7 @@ def main():
         "regime_lr_config": main_rec.get("regime_lr_config"),
         "fine_stage": fine_rec,
         "sdf_mlp_gsamples_per_s": round(sdf_gs, 5),
+        "hbm": hbm,
         "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel / mlp_chain_kernel (fp32 MFMA 32x32x2 layer GEMM tile code with fused epilogue; the chain kernel runs all layers of the refiner's two networks in one launch on the device-side live-ray count), EVERY launch of the timed region with >= 128 rows and > 32 columns and every chain launch; "
                                                 "launches issued while two streams feed the GPU are included (their event intervals can contain the other stream's kernels, "
                                                 "which only lowers the figure); `achieved_alone` restricts to the launches that had the GPU to themselves",

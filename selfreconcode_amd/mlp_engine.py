@@ -218,6 +218,34 @@ def forward(spec, A0, Ws, bs, group):
     return acts
 
 
+# Weight-gradient GEMMs on a stream of their own.  In a reverse sweep dW_l = Zbar_l^T X_{l-1} and the backward-data GEMM
+# Zbar_{l-1} = (Zbar_l W_l) . act' depend on the same Zbar_l and on nothing of each other; on one stream they alternate, every launch
+# drains the machine before the next one fills it (the last partial wave of 128x128 tiles of an 85k-row batch leaves ~5 % of a launch
+# idle, plus the launch gap).  With the weight gradients on a second stream the backward-data chain is the critical path and the
+# weight-gradient workgroups fill its tails.  Only in deferred mode (the results land in the per-layer buffers, nobody reads them
+# before flush_param_grads, which joins the stream); all weight-gradient launches share ONE stream, so the accumulation order into
+# a buffer is the program order -- results are bit-identical to the one-stream schedule.
+TN_SIDE_STREAM = __import__("os").environ.get("SR_TN_STREAM", "1") != "0"
+_TN_STREAMS = {}
+_TN_PENDING = set()
+
+
+def _tn_stream(device):
+    key = str(device)
+    st = _TN_STREAMS.get(key)
+    if st is None:
+        st = _TN_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_weight_gradient_stream():
+    """The current stream of every device with outstanding weight-gradient launches waits for them."""
+    for key in list(_TN_PENDING):
+        st = _TN_STREAMS[key]
+        torch.cuda.current_stream(st.device).wait_stream(st)
+    _TN_PENDING.clear()
+
+
 def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_grad=True, Ws=None, bs=None):
     """One reverse sweep.  Ybar [R, >= N_L] (pitch % 4): cotangent of the output rows.  WTs[l] = W_l^T as
     [K_l, pad4(N_l)].  Returns (A0bar [R, pad4(K0)] or None, dWs [N_l, pad4(K_l)], dbs [N_l])."""
@@ -234,7 +262,16 @@ def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_g
             X = A0 if l == 0 else acts[l - 1]
             if need_param_grad:
                 sink = _deferred_sink(Ws[l], bs[l]) if (DEFERRED_PARAM_GRADS and Ws is not None) else None
-                if sink is not None:          # accumulate straight into the per-step gradient buffers (no autograd traffic)
+                if sink is not None and TN_SIDE_STREAM and not PROFILE.enabled:
+                    main, side = torch.cuda.current_stream(A0.device), _tn_stream(A0.device)
+                    ready = torch.cuda.Event()
+                    ready.record(main)                                   # Zbar (and, for a partial first use, the zeroed buffers) are final here
+                    side.wait_event(ready)
+                    with torch.cuda.stream(side):
+                        _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group, dW=sink[0], db=sink[1], accumulate=sink[2])
+                    Zbar.record_stream(side); X.record_stream(side)      # both may be freed by the main stream's owner before the side stream has read them
+                    _TN_PENDING.add(str(A0.device))
+                elif sink is not None:        # accumulate straight into the per-step gradient buffers (no autograd traffic)
                     _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group, dW=sink[0], db=sink[1], accumulate=sink[2])
                 else:
                     dWs[l], dbs[l] = _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group)
@@ -592,6 +629,7 @@ def flush_param_grads(only=None):
     todo = [e for e in _PACK_CACHE.values() if e.get("dirty") and (only is None or id(e["src"][0]) in only)]
     if not todo:
         return
+    join_weight_gradient_stream()
     for i in range(0, len(todo), _lib.SR_PACK_MAX_LAYERS):
         chunk = todo[i:i + _lib.SR_PACK_MAX_LAYERS]
         t = _lib.SrUnpackTable()
