@@ -562,9 +562,12 @@ def refresh_packs(lins):
             e["sig"] = sig
 
 
+PLAIN_PACKS = __import__("os").environ.get("SR_PLAIN_PACKS", "1") != "0"
+
+
 def pack_linear(lin):
     """Padded effective weight of an nn.Linear, weight-normed (network.py:65-66) or plain."""
-    if DEFERRED_PARAM_GRADS:
+    if DEFERRED_PARAM_GRADS and PLAIN_PACKS:
         # Deferred mode: the weight gradients of every use go into the entry's buffers and reach (v, g) through flush_param_grads,
         # so an up-to-date pack is handed out as a plain tensor -- no autograd node per layer and call (~12 us of host time each,
         # ~250 of them per iteration).  reverse() refuses to drop a gradient silently if such a weight ever comes without a sink.

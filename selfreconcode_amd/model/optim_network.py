@@ -30,6 +30,9 @@ from ..utils.FindSurfacePs import FindSurfacePs, OptimizeSurfacePs
 from .CameraMine import RectifiedPerspectiveCameras
 
 
+_SIDE_STREAMS = {}
+
+
 def scatter_mean(vals, index, dim_size):
     """torch_scatter.scatter(reduce='mean', dim_size=N) as used at network.py:617,637 (empty bins give 0)."""
     s = torch.zeros(dim_size, dtype=vals.dtype, device=vals.device).index_add(0, index, vals)
@@ -191,9 +194,11 @@ class OptimNetwork(nn.Module):
 
     # ------------------------------------------------------------------ rasterisation stand-ins
     def _side_stream(self, device, which=0):
-        st = getattr(self, "_side_streams", None)
-        if st is None:
-            st = self._side_streams = {}
+        # One set of streams per PROCESS and device, not per network object: the runtime multiplexes streams onto a few hardware
+        # queues, and a second network's fresh streams can land on the queue of the weight-gradient stream (mlp_engine) -- its
+        # small refiner launches then queue behind 1 ms weight-gradient kernels (measured: fine stage 52 -> 70 ms when it ran after a
+        # coarse-stage network in the same process).
+        st = _SIDE_STREAMS
         key = (str(device), which)
         if key not in st:
             # high priority: the ray selection on this stream is a handful of tiny kernels with a host round trip after each
