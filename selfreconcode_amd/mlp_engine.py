@@ -19,6 +19,7 @@ all the derivative orders the reference reaches through autograd:
 """
 import math
 import ctypes
+import os
 import torch
 
 from . import _lib
@@ -225,7 +226,7 @@ def forward(spec, A0, Ws, bs, group):
 # weight-gradient workgroups fill its tails.  Only in deferred mode (the results land in the per-layer buffers, nobody reads them
 # before flush_param_grads, which joins the stream); all weight-gradient launches share ONE stream, so the accumulation order into
 # a buffer is the program order -- results are bit-identical to the one-stream schedule.
-TN_SIDE_STREAM = __import__("os").environ.get("SR_TN_STREAM", "1") != "0"
+TN_SIDE_STREAM = os.environ.get("SR_TN_STREAM", "1") != "0"
 _TN_STREAMS = {}
 _TN_PENDING = set()
 
@@ -562,7 +563,7 @@ def refresh_packs(lins):
             e["sig"] = sig
 
 
-PLAIN_PACKS = __import__("os").environ.get("SR_PLAIN_PACKS", "1") != "0"
+PLAIN_PACKS = os.environ.get("SR_PLAIN_PACKS", "1") != "0"
 
 
 def pack_linear(lin):

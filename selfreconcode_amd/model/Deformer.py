@@ -1,5 +1,7 @@
 """Non-rigid deformation field -- drop-in for model/Deformer.py (CompositeDeformer :10-20,
 MLPTranslator :22-76, LBSkinner :86-233)."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -9,7 +11,7 @@ from ..mlp_engine import MLPSpec, mlp_apply, pad_cols, pad4, pack_linear
 from ..utils.utils import resolve_band_weights
 
 
-HOIST_FRAME_CODE = __import__('os').environ.get('SR_HOIST_FRAME_CODE', '1') != '0'     # frame-major batches: per-frame code product out of the deformer's first-layer GEMM (MLPTranslator.hoisted_first_layer)
+HOIST_FRAME_CODE = os.environ.get('SR_HOIST_FRAME_CODE', '1') != '0'     # frame-major batches: per-frame code product out of the deformer's first-layer GEMM (MLPTranslator.hoisted_first_layer)
 
 
 class CompositeDeformer(nn.Module):

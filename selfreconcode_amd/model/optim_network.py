@@ -14,6 +14,8 @@ Deliberate differences (all documented in DESIGN.md):
     `datas['frags']` and then go through FindSurfacePs as in the reference;
   * random draws can be injected (`rand=`) so that parity tests feed both sides the same numbers.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -204,7 +206,7 @@ class OptimNetwork(nn.Module):
             # high priority: the ray selection on this stream is a handful of tiny kernels with a host round trip after each
             # (nonzero); at equal priority each of them queues behind the template branch's thousands of GEMM workgroups and the
             # refiner that follows is not even issued before that branch has drained
-            prio = int(__import__('os').environ.get('SR_SIDE_STREAM_PRIORITY', '-1'))
+            prio = int(os.environ.get('SR_SIDE_STREAM_PRIORITY', '-1'))
             st[key] = torch.cuda.Stream(device=device, priority=prio)
         return st[key]
 

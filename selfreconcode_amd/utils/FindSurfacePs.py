@@ -4,9 +4,10 @@ FindSurfacePs   (:5-29)   rasteriser fragments -> canonical seed points.
 OptimizeSurfacePs (:114-163) the masked Newton refiner ("the tracer").  When given this package's
 ImplicitNetwork + CompositeDeformer([MLPTranslator, LBSkinner]) it runs the device-driven path
 (`_optimize_device_driven`): the queue of unfinished rays is compacted on the GPU after every step and
-every row count stays in device memory; per Newton step the host issues five launches -- first-layer
-inputs of both networks, ONE persistent chain over all forward layers of the sdf-only SDF MLP and the
-deformation MLP side by side, LBS + Jacobian + convergence test + residual cotangents, one persistent
+every row count stays in device memory; per Newton step the host issues a fixed sequence -- first-layer
+inputs of both networks, a chain over all forward layers of the sdf-only SDF MLP and the deformation MLP
+side by side (one launch per layer pair on the device-side row count; `SR_CHAIN_PERSISTENT=1`: ONE
+persistent launch with device-wide barriers), LBS + Jacobian + convergence test + residual cotangents, the
 chain over all reverse layers, Newton update + retirement + compaction -- with no autograd graph, no
 per-frame Python loop and no host synchronisation.  The convergence test of step k and the gradient
 of step k+1 come from the same evaluation (the reference evaluates the same points twice).
@@ -14,6 +15,7 @@ of step k+1 come from the same evaluation (the reference evaluates the same poin
 """
 import ctypes
 import numpy as np
+import os
 import torch
 
 from .. import _lib
@@ -157,9 +159,9 @@ def _newton(ev, x, bi, rays, cam, group, dthr, athr, w1, w2, update):
 # (csrc/refiner.hip + the layer chains of csrc/mlp_gemm.hip); the host issues a FIXED sequence of launches per call
 # (3 small kernels + 2 chains per Newton step) and never synchronises.
 DEVICE_DRIVEN = True
-CHAIN_PERSISTENT = __import__("os").environ.get("SR_CHAIN_PERSISTENT", "0") == "1"   # whole chain in one launch behind device-wide barriers
+CHAIN_PERSISTENT = os.environ.get("SR_CHAIN_PERSISTENT", "0") == "1"   # whole chain in one launch behind device-wide barriers
                                                                                    # (56 launches per call instead of ~230, but slower: see DESIGN.md)
-CHAIN_POLL_MODE = int(__import__("os").environ.get("SR_CHAIN_POLL", "0"))     # tuning switch of the chain kernel's device-wide barrier
+CHAIN_POLL_MODE = int(os.environ.get("SR_CHAIN_POLL", "0"))     # tuning switch of the chain kernel's device-wide barrier
 _WORKSPACES = {}     # (device, capacity) -> _RefinerWorkspace
 _ERROR_WATCH = {}    # device -> (pinned int32, event) of the previous call's barrier-failure flag
 

@@ -333,3 +333,35 @@ def test_fused_pack_refresh_and_fused_flush_match_torch_weight_norm():
                 me.flush_param_grads()
     finally:
         me.set_deferred_param_grads(False)
+
+
+def test_weight_gradient_stream_gives_bitwise_the_same_gradients():
+    """Deferred mode with the weight-gradient GEMMs on their own stream (mlp_engine.TN_SIDE_STREAM) against the one-stream
+    schedule: all weight-gradient launches share one stream, so the accumulation order into a layer's buffer is the program order
+    and the flushed parameter gradients are bit-identical -- two uses of the network, one of them through the sdf-only head."""
+    from selfreconcode_amd import mlp_engine as me
+    from selfreconcode_amd.model.network import getTmpSdf
+    torch.manual_seed(5)
+    net = getTmpSdf(DEV, 6, 0.6, 256)
+    xa = (torch.rand(20000, 3, device=DEV) - 0.5) * 1.4
+    xb = (torch.rand(3000, 3, device=DEV) - 0.5) * 1.4
+    grads = {}
+    for flag in (True, False):
+        me.TN_SIDE_STREAM = flag
+        me.set_deferred_param_grads(True)
+        try:
+            for p in net.parameters():
+                p.grad = None
+            la = net(xa, 1.0, sdf_only=True).abs().mean()
+            yb = net(xb, 1.0)
+            lb = (yb ** 2).mean() + (net.rendcond ** 2).mean()
+            (la + lb).backward()
+            me.flush_param_grads()
+            torch.cuda.synchronize()
+            grads[flag] = [p.grad.clone() for p in net.parameters()]
+        finally:
+            me.set_deferred_param_grads(False)
+            me.TN_SIDE_STREAM = True
+    assert all(g is not None and torch.isfinite(g).all() for g in grads[True])
+    for a, b in zip(grads[True], grads[False]):
+        assert torch.equal(a, b)
