@@ -26,7 +26,8 @@ The timed window always contains exactly one remesh when K <= the remesh interva
 1/20 instead of 1/30 or 1/120); its duration is reported, with the properly amortised figure beside.  The K timed steps run
 twice: the first pass carries no instrumentation and gives `value` (refiner on the side stream, concurrent with the template
 branch); the second repeats them with HIP-event pairs around every layer-GEMM launch (roofline leg), the remesh and the refiner,
-with the refiner on the main stream so that an event interval is one kernel's duration.
+with the refiner and the weight-gradient GEMMs on the main stream so that an event interval is one kernel's duration.
+Camera focal length, principal point and T are learnable as in config.conf:10-15 (quaternion fixed).
 Inputs are synthetic and resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
 """
 import argparse
