@@ -70,6 +70,21 @@ class OptimNetwork(nn.Module):
         self.info = {}
         self.dataset = None
         self.dctnull = None
+        self.next_conf = None                 # set by utils.checkpoint.set_hierarchical_config: the stage switch takes effect at the
+        self.next_train_conf = None           # next scheduled remesh (update_hierarchical_config, network.py:172-205,464)
+
+    def update_hierarchical_config(self, device=None):
+        """network.py:172-205: adopt the pending stage configuration -- loss weights, point-splat radius, remesh interval -- and
+        restart the iteration counter.  (The reference rebuilds its two pytorch3d renderers here; the rasterisers of this package
+        take the radius / image size per call.)"""
+        if self.next_conf is not None:
+            self.conf = self.next_conf
+            self.forward_time = 0
+            self.point_radius = self.next_train_conf.get_float('point_render.radius')
+            self.remesh_intersect = self.next_train_conf.get_int('point_render.remesh_intersect')
+            self.sdfShrinkRadius = 0.0
+            self.next_conf = None
+            self.next_train_conf = None
 
     # ------------------------------------------------------------------ SDF pre-fit (network.py:207-290, SURVEY 8(f) item 4)
     def initializeTmpSDF(self, nepochs, save_name=None, with_normals=False, verbose=False):
@@ -264,6 +279,7 @@ class OptimNetwork(nn.Module):
             if ev is not None:                       # bench.py: duration of the remesh inside the timed window
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
+            self.update_hierarchical_config(device)          # a pending stage switch takes effect with this remesh (network.py:464)
             self.TmpVs, self.Tmpfs = self.discretizeSDF(ratio, None, -self.sdfShrinkRadius)
             if ev is not None:
                 e1.record(); ev.append((e0, e1))

@@ -37,14 +37,18 @@ def load_model(name, optNet, dataset, device, subsdfmodel=None, model_rm_prefix=
     return optNet, dataset
 
 
-def set_hierarchical_config(conf, name, optNet, resolutions):
-    """Stage switch (coarse -> medium -> fine, utils/utils.py:237-255): loss weights, point radius, remesh interval and a new
-    Seg3dLossless engine at the stage's resolution pyramid; returns the stage's batch size."""
+def set_hierarchical_config(conf, name, optNet, dataloader, resolutions):
+    """Stage switch coarse -> medium -> fine (utils/utils.py:237-255), same signature and return value: a DataLoader over the same
+    dataset / sampler with the stage's batch size (None stays None: the synthetic sequence has no loader), the stage's loss /
+    point-render configuration left PENDING on the network (`next_conf`, `next_train_conf`: OptimNetwork adopts them at its next
+    scheduled remesh, network.py:464) and a new Seg3dLossless engine at the stage's resolution pyramid, in place at once."""
     from ..MCAcc import Seg3dLossless
-    optNet.conf = conf.get_config('loss_' + name)
-    optNet.forward_time = 0
-    optNet.point_radius = conf.get_float('train.' + name + '.point_render.radius')
-    optNet.remesh_intersect = conf.get_int('train.' + name + '.point_render.remesh_intersect')
+    batch_size = conf.get_int('train.' + name + '.point_render.batch_size')
+    if dataloader is not None:
+        dataloader = torch.utils.data.DataLoader(dataloader.dataset, batch_size, sampler=dataloader.sampler, num_workers=dataloader.num_workers)
+    optNet.next_conf = conf.get_config('loss_' + name)
+    optNet.next_train_conf = conf.get_config('train.' + name)
     optNet.engine = Seg3dLossless(query_func=None, b_min=optNet.engine.b_min, b_max=optNet.engine.b_max, resolutions=resolutions,
-                                  align_corners=False, balance_value=0.0).to(optNet.engine.b_min.device)
-    return conf.get_int('train.' + name + '.point_render.batch_size')
+                                  align_corners=False, balance_value=0.0,
+                                  use_cuda_impl=getattr(optNet.engine, 'use_cuda_impl', True)).to(optNet.engine.b_min.device)
+    return optNet, dataloader
