@@ -192,7 +192,40 @@ class OptimNetwork(nn.Module):
                 if with_normals:
                     dn, _ = U.compute_deformed_normals(self.sdf, self.deformer, ps_, defconds, bi_, ratio, 'test', cache=jac, onx=nx_raw)
                     nimg[bi_, r_, c_] = dn @ flipRt.t()
-        return {'img': img, 'mask': mask, 'normal': nimg, 'converged': okimg}
+        return {'img': img, 'mask': mask, 'normal': nimg, 'converged': okimg, 'def_verts': defTmpVs}
+
+    def infer(self, TmpVs, Tmpfs, H, W, ratio, frame_ids, notcolor=False, gts=None):
+        """Same call as the reference's `infer` (network.py:306-372): (colors, imgs, def1imgs, defMeshVs).  `colors` [N,H,W,3] uint8 is
+        the rendering-network image of the deformed template (tanh output mapped from [-1,1] to [0,255], background 255 or
+        `gts['image']`), `defMeshVs` the deformed template vertices [N,V,3] (numpy); `gts['maskE']` receives the per-frame mask IoU
+        error of the rasterised silhouette.  `imgs` / `def1imgs` -- the Phong-shaded previews of pytorch3d's mesh renderer -- are not
+        produced (None): third-party shading, outside this path."""
+        with_color = not notcolor
+        if with_color:
+            out = self.render_frames(frame_ids, ratio, TmpVs=TmpVs.detach(), Tmpfs=Tmpfs, chunk=10000, dthreshold=1.e-4, times=30, with_normals=False)
+            masks, defV = out['mask'], out['def_verts']
+        else:
+            device = frame_ids.device
+            N = frame_ids.numel()
+            cameras, H, W = self._cameras(N, device)
+            with torch.no_grad():
+                poses, trans, d_cond, _ = [t.detach() for t in self.dataset.get_grad_parameters(frame_ids, device)]
+                defV = self.deformer(TmpVs.detach()[None, :, :].expand(N, -1, 3), [d_cond, [poses, trans]], ratio=ratio)
+                xy, z = cameras.project_ndc(defV)
+                masks = (rasterize_meshes(xy, z, Tmpfs, H, W).pix_to_face[..., 0] >= 0).float()
+        N = masks.shape[0]
+        if gts:
+            gtMs = gts['mask'].to(masks.device)
+            gts['maskE'] = (1. - (masks * gtMs).view(N, -1).sum(1) / (masks + gtMs - masks * gtMs).abs().view(N, -1).sum(1)).cpu().numpy()
+        defMeshVs = defV.detach().cpu().numpy()
+        if not with_color:
+            return None, None, None, defMeshVs
+        colors = torch.clamp((out['img'] / 2. + 0.5) * 255., min=0., max=255.)
+        covered = masks > 0.
+        colors[~covered] = 255.
+        if gts and 'image' in gts:
+            colors[~covered] = gts['image'].to(colors.device)[~covered][:, :3] * 255.
+        return colors.cpu().numpy().astype(np.uint8), None, None, defMeshVs
 
     def _cameras(self, N, device):
         # fixed cameras (no learnable parameter) are built once: quaternion -> R and friends are ~40 tiny launches per call
