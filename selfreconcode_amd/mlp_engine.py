@@ -20,6 +20,7 @@ all the derivative orders the reference reaches through autograd:
 import math
 import ctypes
 import os
+import weakref
 import torch
 
 from . import _lib
@@ -272,7 +273,7 @@ def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_g
                 sink = _deferred_sink(Ws[l], bs[l]) if (DEFERRED_PARAM_GRADS and Ws is not None) else None
                 if sink is None and DEFERRED_PARAM_GRADS and Ws is not None and not Ws[l].requires_grad:
                     e = _ENTRY_BY_PTR.get(Ws[l].data_ptr())
-                    if e is not None and any(t.requires_grad for t in e.get("src", ())):
+                    if e is not None and any(r() is not None and r().requires_grad for r in e.get("src", ())):
                         raise RuntimeError("mlp_engine: a packed weight handed out without autograd node (deferred mode) met a layer call "
                                            "that has no deferred sink (bias that is not the layer's own leaf parameter?): its gradient would be lost")
                 if sink is not None and TN_SIDE_STREAM and not PROFILE.enabled:
@@ -460,8 +461,17 @@ def _sig(*ts):
     return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in ts)
 
 
-def _pack_entry(key, sig, build):
+def _drop_entry(key):
+    e = _PACK_CACHE.pop(key, None)
+    if e is not None:
+        _WT_BY_PTR.pop(e["W"].data_ptr(), None)
+        _ENTRY_BY_PTR.pop(e["W"].data_ptr(), None)
+
+
+def _pack_entry(key, sig, build, owner=None):
     e = _PACK_CACHE.get(key)
+    if e is None and owner is not None:
+        weakref.finalize(owner, _drop_entry, key)      # the entry (packed weights, gradient buffers) goes when its parameter does
     if e is None or e["sig"] != sig:
         if e is not None:
             _WT_BY_PTR.pop(e["W"].data_ptr(), None)
@@ -488,8 +498,8 @@ class PackWeightNorm(torch.autograd.Function):
                 w, norms = torch._weight_norm_interface(v, g, 0)
                 W = pad_cols(w, pad4(K)).contiguous()
                 return {"W": W, "WT": transpose_padded(W, K), "norms": norms}
-        e = _pack_entry(id(v), _sig(v, g), build)
-        e["src"] = (v, g)
+        e = _pack_entry(id(v), _sig(v, g), build, owner=v)
+        e["src"] = (weakref.ref(v), weakref.ref(g))
         ctx.save_for_backward(v, g, e["norms"])
         ctx.set_materialize_grads(False)      # deferred mode hands back None for every use: no zero tensor, no weight-norm backward of zeros
         return e["W"].detach()
@@ -514,8 +524,8 @@ class PackPlain(torch.autograd.Function):
                 if W.data_ptr() == w.data_ptr():
                     W = W.clone()
                 return {"W": W, "WT": transpose_padded(W, K), "norms": None}
-        e = _pack_entry(id(w), _sig(w), build)
-        e["src"] = (w,)
+        e = _pack_entry(id(w), _sig(w), build, owner=w)
+        e["src"] = (weakref.ref(w),)
         ctx.K = K
         ctx.set_materialize_grads(False)
         return e["W"].detach()
@@ -654,7 +664,7 @@ def _deferred_sink(W, b):
 def flush_param_grads(only=None):
     """`only`: ids of parameter tensors (weight_v / weight) whose layers are flushed now; the rest stays pending.
     All pending layers are turned into parameter gradients by ONE launch (sr_unpack_grads: weight-norm backward / plain copy)."""
-    todo = [e for e in _PACK_CACHE.values() if e.get("dirty") and (only is None or id(e["src"][0]) in only)]
+    todo = [e for e in _PACK_CACHE.values() if e.get("dirty") and (only is None or id(e["src"][0]()) in only)]
     if not todo:
         return
     join_weight_gradient_stream()
@@ -665,7 +675,7 @@ def flush_param_grads(only=None):
         outs = []
         for j, e in enumerate(chunk):
             L = t.layer[j]
-            src = e["src"]
+            src = tuple(r() for r in e["src"])          # (weak references: an entry must not keep its parameters alive)
             v = src[0]
             g = src[1] if len(src) == 2 else None
             acc = v.grad is not None and (g is None or g.grad is not None)

@@ -77,3 +77,23 @@ def test_ctypes_structs_have_the_size_the_header_declares(tmp_path):
     sizes = dict(line.split() for line in out.strip().splitlines())
     for n, cls in pairs.items():
         assert int(sizes[n]) == ctypes.sizeof(cls), (n, sizes[n], ctypes.sizeof(cls))
+
+
+def test_pack_cache_entries_die_with_their_parameters():
+    """mlp_engine keeps packed weights / gradient buffers per parameter; the entry must not outlive (or keep alive) the module."""
+    import gc
+    import torch
+    from selfreconcode_amd import mlp_engine as me
+
+    class Stub:                       # what _pack_entry needs of an entry, without a GPU
+        pass
+    lin = torch.nn.Linear(8, 4)
+    key = id(lin.weight)
+    W = torch.zeros(4, 8)
+    e = me._pack_entry(key, ("sig",), lambda: {"W": W, "WT": W.t().contiguous(), "norms": None}, owner=lin.weight)
+    assert key in me._PACK_CACHE and me._ENTRY_BY_PTR[W.data_ptr()] is e
+    import weakref
+    e["src"] = (weakref.ref(lin.weight),)
+    del lin
+    gc.collect()
+    assert key not in me._PACK_CACHE and W.data_ptr() not in me._ENTRY_BY_PTR and W.data_ptr() not in me._WT_BY_PTR
