@@ -255,3 +255,57 @@ for name, mod in (("sdf", ref.network.getTmpSdf("cpu", 6, 0.6, 256)), ("translat
 with open(os.path.join(OUT, "state_keys.json"), "w") as fh:
     json.dump(keys, fh, indent=0, sort_keys=True)
 print("wrote state_keys.json", {k: len(v) for k, v in keys.items()})
+
+# ---------------------------------------------------------------- a15 propagateTmpPsGrad run verbatim (network.py:702-814)
+# The method is called on a bare OptimNetwork object (its constructor needs the pytorch3d renderers): det-parameter SDF and
+# translator, the small LBS volume, a 5-frame dataset stand-in with the reference's accessors (dataset/dataset.py:117-127) and
+# learnable focal length / principal point / T as in config.conf:10-15, so the ray / camera-centre terms (:798-813) are exercised.
+import types
+
+ref.network.Fast3x3Minv = lambda m: list(orc.minv3x3(m))
+Fn, Hh, Ww = 5, 64, 48
+
+
+class _Seq:
+    def __init__(self):
+        leaf = lambda t: t.clone().requires_grad_(True)
+        self.poses = leaf(fx.det_tensor((Fn, 24, 3), 71, 0.15)); self.trans = leaf(fx.det_tensor((Fn, 3), 72, 0.05))
+        self.conds = [leaf(fx.det_tensor((Fn, 128), 73, 0.1)), leaf(fx.det_tensor((Fn, 256), 74, 0.1))]
+        self.focal = leaf(torch.tensor([58.0, 60.0])); self.princ = leaf(torch.tensor([23.0, 33.5])); self.T = leaf(torch.tensor([0.03, -0.1, 2.5]))
+        self.R = orc.quat2mat(torch.tensor([[0.02, 0.01, 0.999, 0.03]]))
+
+    def get_grad_parameters(self, idxs, device):
+        return self.poses[idxs], self.trans[idxs], self.conds[0][idxs], self.conds[1][idxs]
+
+    def get_camera_parameters(self, N, device):
+        return self.focal.view(1, 2).expand(N, 2), self.princ.view(1, 2).expand(N, 2), self.R.expand(N, 3, 3), self.T.view(1, 3).expand(N, 3), Hh, Ww
+
+
+seq = _Seq()
+for m in (sdf, tr):
+    for prm in m.parameters():
+        prm.grad = None
+onet = object.__new__(ref.network.OptimNetwork)
+torch.nn.Module.__init__(onet)
+onet.sdf, onet.deformer, onet.dataset, onet.info = sdf, comp, seq, {}
+onet.maskRender = types.SimpleNamespace(rasterizer=types.SimpleNamespace(cameras=None))
+Pq = 36
+fids = torch.tensor([4, 0, 2])
+onet.batch_inds = torch.tensor([i % 3 for i in range(Pq)])
+onet.col_inds = (fx.det_tensor((Pq,), 75, 0.5) * Ww + Ww / 2).long().clamp(0, Ww - 1)
+onet.row_inds = (fx.det_tensor((Pq,), 76, 0.5) * Hh + Hh / 2).long().clamp(0, Hh - 1)
+onet.TmpPs = (fx.det_tensor((Pq, 3), 77, 0.35) * torch.tensor([0.7, 1.0, 0.3])).requires_grad_(True)
+onet.TmpPs.grad = fx.det_tensor((Pq, 3), 78, 1.0)
+cam0 = ref.network.RectifiedPerspectiveCameras(*seq.get_camera_parameters(3, 'cpu')[:4], image_size=[(Ww, Hh)])
+onet.rays = cam0.view_rays(torch.cat([onet.col_inds.view(-1, 1), onet.row_inds.view(-1, 1), torch.ones(Pq, 1, dtype=torch.long)], dim=-1).float())
+assert onet.rays.requires_grad
+onet.propagateTmpPsGrad(fids, ratio)
+sp, tp = dict(sdf.named_parameters()), dict(tr.named_parameters())
+save("propagate", fids=fids, bi=onet.batch_inds, cols=onet.col_inds, rows=onet.row_inds, p=onet.TmpPs.detach(), glp=fx.det_tensor((Pq, 3), 78, 1.0),
+     poses=seq.poses.detach(), trans=seq.trans.detach(), dcond=seq.conds[0].detach(), rcond=seq.conds[1].detach(),
+     focal=seq.focal.detach(), princ=seq.princ.detach(), T=seq.T.detach(), R=seq.R[0], HW=np.array([Hh, Ww]),
+     inv_info=np.array(onet.info['invInfo']),
+     g_poses=seq.poses.grad, g_trans=seq.trans.grad, g_dcond=seq.conds[0].grad, g_focal=seq.focal.grad, g_princ=seq.princ.grad, g_T=seq.T.grad,
+     g_sdf_v0=sp['lin0.weight_v'].grad[::37, ::5], g_sdf_g4=sp['lin4.weight_g'].grad, g_sdf_b7=sp['lin7.bias'].grad, g_sdf_v8=sp['lin8.weight_v'].grad[:1, ::7],
+     g_tr_w0=tp['lin0.weight'].grad[::41, ::9], g_tr_w2=tp['lin2.weight'].grad[::53, ::47], g_tr_b4=tp['lin4.bias'].grad, g_tr_w4=tp['lin4.weight'].grad[:, ::11])
+print("rcond grad:", None if seq.conds[1].grad is None else float(seq.conds[1].grad.abs().max()))

@@ -55,7 +55,16 @@ def load_reference():
 
     class CamerasBase(torch.nn.Module):  # pytorch3d.renderer.cameras.CamerasBase must be a real class
         def __init__(self, *a, **k):
+            """pytorch3d's TensorProperties keeps the constructor's keyword tensors as attributes (focal_length, principal_point, R, T,
+            image_size ...): that much is needed for RectifiedPerspectiveCameras(...).view_rays / cam_pos to run."""
             super().__init__()
+            for name, value in k.items():
+                if name == "image_size" and not torch.is_tensor(value):
+                    value = torch.tensor(value)
+                object.__setattr__(self, name, value)
+
+        def to(self, device):
+            return self
 
     for name in [
         "pytorch3d", "pytorch3d.structures", "pytorch3d.loss", "pytorch3d.io", "pytorch3d.renderer",

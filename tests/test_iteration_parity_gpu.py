@@ -169,3 +169,74 @@ def test_whole_iteration_with_injected_randoms_vs_oracle():
         assert ds.conds[1].grad is None or float(ds.conds[1].grad.abs().max()) == 0.0     # rendcond[batch_inds] is passed and ignored (utils.py:171-172)
     finally:
         mlp_engine.set_deferred_param_grads(False)
+
+
+def test_propagate_tmp_ps_grad_vs_the_references_own_run(golden):
+    """a15 against the reference ITSELF: tests/golden/propagate.npz holds the gradients that the reference's
+    OptimNetwork.propagateTmpPsGrad (model/network.py:702-814) deposited when run verbatim on CPU (oracle/gen_golden.py) -- SDF,
+    deformation MLP, poses / translations / codes and the learnable focal length / principal point / T.  The product runs the same
+    call (fused implicit solve, forward-mode Jacobian, deferred weight gradients on their own stream) on the same inputs."""
+    import numpy as np
+    from selfreconcode_amd import mlp_engine
+    from selfreconcode_amd.model.network import getTmpSdf
+    from selfreconcode_amd.model.Deformer import MLPTranslator, LBSkinner, CompositeDeformer
+    from selfreconcode_amd.model.optim_network import OptimNetwork
+    from selfreconcode_amd.utils import smpl_tmp_Apose
+    g = golden("propagate")
+    sdf = getTmpSdf(DEV, 6, 0.6, 256)
+    sdf.load_state_dict(fx.det_params(fx.SDF_SPEC, 101), strict=True)
+    tr = MLPTranslator(128, 6).to(DEV)
+    tr.load_state_dict(fx.det_params(fx.DEF_SPEC, 202), strict=True)
+    skin = LBSkinner(fx.synthetic_lbs_volume((7, 11, 9)), fx.LBS_BMIN, fx.LBS_BMAX, fx.synthetic_joints(), np.array(fx.SMPL_PARENTS),
+                     init_pose=torch.from_numpy(smpl_tmp_Apose(1)), align_corners=False).to(DEV)
+    leaf = lambda t: t.to(DEV).clone().requires_grad_(True)
+
+    class Seq:                                                        # the accessors of dataset/dataset.py:76-81,117-127
+        poses, trans, conds = leaf(g["poses"]), leaf(g["trans"]), [leaf(g["dcond"]), leaf(g["rcond"])]
+        camera_params = {'focal_length': leaf(g["focal"]), 'princeple_points': leaf(g["princ"]), 'world2cam_coord_trans': leaf(g["T"])}
+        R = g["R"].to(DEV)
+        H, W = int(g["HW"][0]), int(g["HW"][1])
+
+        def get_grad_parameters(self, idxs, device=None):
+            return self.poses[idxs], self.trans[idxs], self.conds[0][idxs], self.conds[1][idxs]
+
+        def get_camera_parameters(self, N, device=None):
+            c = self.camera_params
+            return (c['focal_length'].view(1, 2).expand(N, 2), c['princeple_points'].view(1, 2).expand(N, 2), self.R.view(1, 3, 3).expand(N, 3, 3),
+                    c['world2cam_coord_trans'].view(1, 3).expand(N, 3), self.H, self.W)
+
+        def learnable_weights(self):
+            return [self.conds[0], self.conds[1]] + list(self.camera_params.values()) + [self.poses, self.trans]
+    ds = Seq()
+    net = OptimNetwork(sdf, CompositeDeformer([tr, skin]).to(DEV), None, None, None, conf=None)
+    net.dataset = ds
+    fids = g["fids"].long().to(DEV)
+    net.batch_inds, net.col_inds, net.row_inds = g["bi"].long().to(DEV), g["cols"].long().to(DEV), g["rows"].long().to(DEV)
+    net.TmpPs = g["p"].to(DEV).clone().requires_grad_(True)
+    net.TmpPs.grad = g["glp"].to(DEV).clone()
+    cameras, _, _ = net._cameras(3, torch.device(DEV))
+    net.rays = cameras.view_rays(torch.stack([net.col_inds, net.row_inds, torch.ones_like(net.col_inds)], dim=-1).float())
+    assert net.rays.requires_grad
+    for deferred in (True, False):
+        for t in list(sdf.parameters()) + list(tr.parameters()) + ds.learnable_weights():
+            t.grad = None
+        net.TmpPs.grad = g["glp"].to(DEV).clone()
+        mlp_engine.set_deferred_param_grads(deferred)
+        try:
+            net.info = {}
+            net.propagateTmpPsGrad(fids, RATIO)
+        finally:
+            mlp_engine.set_deferred_param_grads(False)
+        assert int(net.info['invInfo'][0]) == int(g["inv_info"][0]) and abs(int(net.info['invInfo'][1]) - int(g["inv_info"][1])) <= 1
+        sp, tp = dict(sdf.named_parameters()), dict(tr.named_parameters())
+        tol = dict(rtol=3e-3, frac=3e-3)                               # float32 through (b^T b)^-1 on both sides (the CPU oracle meets the same fixture to 2e-3)
+        close(ds.poses.grad, g["g_poses"], name="poses", **tol); close(ds.trans.grad, g["g_trans"], name="trans", **tol)
+        close(ds.conds[0].grad, g["g_dcond"], name="dcond", **tol)
+        close(ds.camera_params['focal_length'].grad, g["g_focal"], name="focal", **tol)
+        close(ds.camera_params['princeple_points'].grad, g["g_princ"], name="princ", **tol)
+        close(ds.camera_params['world2cam_coord_trans'].grad, g["g_T"], name="T", **tol)
+        close(sp['lin0.weight_v'].grad[::37, ::5], g["g_sdf_v0"], name="sdf v0", **tol); close(sp['lin4.weight_g'].grad, g["g_sdf_g4"], name="sdf g4", **tol)
+        close(sp['lin7.bias'].grad, g["g_sdf_b7"], name="sdf b7", **tol); close(sp['lin8.weight_v'].grad[:1, ::7], g["g_sdf_v8"], name="sdf v8", **tol)
+        close(tp['lin0.weight'].grad[::41, ::9], g["g_tr_w0"], name="tr w0", **tol); close(tp['lin2.weight'].grad[::53, ::47], g["g_tr_w2"], name="tr w2", **tol)
+        close(tp['lin4.bias'].grad, g["g_tr_b4"], name="tr b4", **tol); close(tp['lin4.weight'].grad[:, ::11], g["g_tr_w4"], name="tr w4", **tol)
+        assert ds.conds[1].grad is None or float(ds.conds[1].grad.abs().max()) == 0.0

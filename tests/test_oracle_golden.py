@@ -195,3 +195,36 @@ def test_seg3d_restatement(golden):
                              0.0, stats=st)
     assert st["queries"] == int(g["nq"])
     close(vol[0, 0], g["vol"], rtol=0, atol=0)
+
+
+def test_propagate_tmp_ps_grad_vs_the_references_own_run(golden):
+    """a15: oracle/iteration_oracle.py::propagate against tests/golden/propagate.npz = OptimNetwork.propagateTmpPsGrad of the reference
+    run verbatim on CPU (model/network.py:702-814), with learnable focal length / principal point / T: gradients of the SDF, the
+    deformation MLP, poses / translations / codes and the three camera tensors (the ray and camera-centre terms, :798-813)."""
+    from oracle import iteration_oracle as ito
+    g = golden("propagate")
+    leaf = lambda t: t.clone().requires_grad_(True)
+    sdf = {k: leaf(v) for k, v in fx.det_params(fx.SDF_SPEC, 101).items()}
+    tr = {k: leaf(v) for k, v in fx.det_params(fx.DEF_SPEC, 202).items()}
+    skin = _lbs_setup(golden("lbs"))
+    cam = dict(focal=leaf(g["focal"]), princ=leaf(g["princ"]), R=g["R"], T=leaf(g["T"]), H=int(g["HW"][0]), W=int(g["HW"][1]))
+    sc = ito.Scene(sdf, tr, None, skin, leaf(g["poses"]), leaf(g["trans"]), leaf(g["dcond"]), leaf(g["rcond"]), cam, None, 0.0, 0.0)
+    p = g["p"].clone().requires_grad_(True)
+    p.grad = g["glp"].clone()
+    cols, rows, bi = g["cols"].long(), g["rows"].long(), g["bi"].long()
+    state = dict(TmpPs=p, rays=sc.rays(cols, rows), bi=bi, rows=rows, cols=cols)
+    assert state["rays"].requires_grad
+    n_sys, n_ok = ito.propagate(sc, state, g["fids"].long(), RATIO)
+    assert [n_sys, n_ok] == [int(v) for v in g["inv_info"]]
+
+    def rel(a, b, tol=2e-3, name=""):              # float32 on both sides through (b^T b)^-1 of the normal equations: ~1e-3 of the largest entry
+        scale = float(b.abs().max())
+        assert scale > 0, name
+        assert float((a - b).abs().max()) <= tol * scale, (name, float((a - b).abs().max()), scale)
+    rel(sc.poses.grad, g["g_poses"], name="poses"); rel(sc.trans.grad, g["g_trans"], name="trans"); rel(sc.dcond.grad, g["g_dcond"], name="dcond")
+    rel(cam["focal"].grad, g["g_focal"], name="focal"); rel(cam["princ"].grad, g["g_princ"], name="princ"); rel(cam["T"].grad, g["g_T"], name="T")
+    rel(sdf["lin0.weight_v"].grad[::37, ::5], g["g_sdf_v0"], name="sdf v0"); rel(sdf["lin4.weight_g"].grad, g["g_sdf_g4"], name="sdf g4")
+    rel(sdf["lin7.bias"].grad, g["g_sdf_b7"], name="sdf b7"); rel(sdf["lin8.weight_v"].grad[:1, ::7], g["g_sdf_v8"], name="sdf v8")
+    rel(tr["lin0.weight"].grad[::41, ::9], g["g_tr_w0"], name="tr w0"); rel(tr["lin2.weight"].grad[::53, ::47], g["g_tr_w2"], name="tr w2")
+    rel(tr["lin4.bias"].grad, g["g_tr_b4"], name="tr b4"); rel(tr["lin4.weight"].grad[:, ::11], g["g_tr_w4"], name="tr w4")
+    assert sc.rcond.grad is None                      # the render codes take no part in this pass
