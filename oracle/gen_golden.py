@@ -309,3 +309,64 @@ save("propagate", fids=fids, bi=onet.batch_inds, cols=onet.col_inds, rows=onet.r
      g_sdf_v0=sp['lin0.weight_v'].grad[::37, ::5], g_sdf_g4=sp['lin4.weight_g'].grad, g_sdf_b7=sp['lin7.bias'].grad, g_sdf_v8=sp['lin8.weight_v'].grad[:1, ::7],
      g_tr_w0=tp['lin0.weight'].grad[::41, ::9], g_tr_w2=tp['lin2.weight'].grad[::53, ::47], g_tr_b4=tp['lin4.bias'].grad, g_tr_w4=tp['lin4.weight'].grad[:, ::11])
 print("rcond grad:", None if seq.conds[1].grad is None else float(seq.conds[1].grad.abs().max()))
+
+# ---------------------------------------------------------------- a14 computeTmpPcLoss run verbatim (network.py:647-697)
+# Bare OptimNetwork again; `imgs[..., -1]` (the point-silhouette masks, pytorch3d in the reference) come from the oracle's restated
+# renderer so that the inner backward has a path into the deformer; everything the method itself does -- IoU loss, deformation
+# consistency, inner backward, template SGD step, |f(TmpVs)| -- is the reference's code on the reference's modules.
+from oracle import raster_oracle as ro  # noqa: E402
+
+
+class _DictConf:
+    """get_float / `in` on dotted keys, as pyhocon's ConfigTree serves them (config.conf:79-88 values)."""
+
+    def __init__(self, d):
+        self.d = d
+
+    def _find(self, key):
+        cur = self.d
+        for part in key.split('.'):
+            if not isinstance(cur, dict) or part not in cur:
+                return None
+            cur = cur[part]
+        return cur
+
+    def __contains__(self, key):
+        return self._find(key) is not None
+
+    def get_float(self, key):
+        return float(self._find(key))
+
+
+for m in (sdf, tr):
+    for prm in m.parameters():
+        prm.grad = None
+seq2 = _Seq()
+pcnet = object.__new__(ref.network.OptimNetwork)
+torch.nn.Module.__init__(pcnet)
+pcnet.sdf, pcnet.deformer, pcnet.info = sdf, comp, {'pc_loss': {}}
+pcnet.conf = _DictConf({'pc_weight': {'weight': 60., 'laplacian_weight': -10., 'edge_weight': -10., 'norm_weight': -0.001,
+                                      'def_consistent': {'weight': 0.6, 'c': 0.01}}})
+pcnet.sdfShrinkRadius = 0.0
+Vn, Np, Hp, Wp, rad = 400, 2, 40, 40, 0.08
+dirs_v = torch.nn.functional.normalize(fx.det_tensor((Vn, 3), 81, 1.0), dim=1)
+pcnet.TmpVs = (dirs_v * torch.tensor([0.28, 0.42, 0.16]) + fx.det_tensor((Vn, 3), 82, 0.01)).requires_grad_(True)
+pcnet.Tmpfs = torch.zeros(1, 3, dtype=torch.long)
+pcnet.TmpOptimizer = torch.optim.SGD([pcnet.TmpVs], lr=0.05, momentum=0.9)
+V0 = pcnet.TmpVs.detach().clone()
+fid2 = torch.tensor([3, 1])
+poses2, trans2, dcond2, _ = seq2.get_grad_parameters(fid2, 'cpu')
+defc = [dcond2, [poses2, trans2]]
+defV = comp(pcnet.TmpVs[None].expand(Np, -1, 3), defc, ratio=ratio)
+focal_p, princ_p, T_p = torch.tensor([52.0, 50.0]), torch.tensor([17.5, 20.5]), torch.tensor([0.02, -0.05, 2.4])
+masks_p, _ = ro.render_point_silhouette(defV, focal_p, princ_p, seq2.R[0], T_p, Hp, Wp, rad, 50)
+gt_p = (fx.det_tensor((Np, Hp, Wp), 83, 1.0) > 0.2).float()
+out_p = pcnet.computeTmpPcLoss(types.SimpleNamespace(verts_padded=lambda: defV), defc, masks_p[..., None], gt_p, ratio)
+inner = dict(g_tr_w0=tp['lin0.weight'].grad[::41, ::9].clone(), g_tr_w2=tp['lin2.weight'].grad[::53, ::47].clone(), g_tr_b4=tp['lin4.bias'].grad.clone(),
+             g_poses=seq2.poses.grad.clone(), g_trans=seq2.trans.grad.clone(), g_dcond=seq2.conds[0].grad.clone())
+out_p.backward()
+save("pcloss", V0=V0, fids=fid2, poses=seq2.poses.detach(), trans=seq2.trans.detach(), dcond=seq2.conds[0].detach(), focal=focal_p, princ=princ_p,
+     T=T_p, R=seq2.R[0], HW=np.array([Hp, Wp]), radius=np.array(rad), gt=gt_p, masks=masks_p.detach(),
+     mask_loss=np.array(pcnet.info['pc_loss']['mask_loss']), defconst_loss=np.array(pcnet.info['pc_loss']['defconst_loss']),
+     pc_loss_sdf=np.array(pcnet.info['pc_loss_sdf']), out=out_p.detach(), V1=pcnet.TmpVs.detach(), **inner,
+     g_sdf_v0=sp['lin0.weight_v'].grad[::37, ::5], g_sdf_g4=sp['lin4.weight_g'].grad, g_sdf_b7=sp['lin7.bias'].grad, g_sdf_v8=sp['lin8.weight_v'].grad[:1, ::7])

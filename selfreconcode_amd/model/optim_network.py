@@ -287,6 +287,8 @@ class OptimNetwork(nn.Module):
     def forward(self, datas, sample_pix, ratio, frame_ids, root=None, rand=None, debug=None, **kwargs):
         """`rand` (extension): dict of pre-drawn random tensors (ray_select, vert_select, vert_select2, eik_local, eik_global,
         regu_local; each may be longer than needed, the head is used) so that a parity test feeds both sides the same numbers;
+        `rand['refined'] = (points, flags)` replaces the refiner's output for the selected rays (its |f| < 5e-5 acceptance flips
+        on single ulps: tests compare the refiner separately and everything after it on identical ray sets);
         `debug` (extension): a dict that receives the selected rays, their seeds and the refiner's output."""
         device = frame_ids.device
         rand = rand or {}
@@ -392,9 +394,13 @@ class OptimNetwork(nn.Module):
             if rev is not None:                  # bench.py: time the refiner occupies on its stream
                 r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 r0.record(rstream)
-            initTmpPs, check = OptimizeSurfacePs(cameras.cam_pos().detach(), rays.detach(), initTmpPs, batch_inds, self.sdf, ratio,
-                                                 self.deformer, [d_cond_s, [poses_s, trans_s]], dthreshold=5.e-5,
-                                                 athreshold=self.angThred, w1=3.05, w2=1., times=10)
+            if 'refined' in rand:                # parity tests: the refiner's output for exactly these rays, taken from the other side
+                initTmpPs, check = rand['refined'][0].to(device).float().contiguous(), rand['refined'][1].to(device).bool()
+                assert initTmpPs.shape[0] == batch_inds.shape[0] and check.shape[0] == batch_inds.shape[0]
+            else:
+                initTmpPs, check = OptimizeSurfacePs(cameras.cam_pos().detach(), rays.detach(), initTmpPs, batch_inds, self.sdf, ratio,
+                                                     self.deformer, [d_cond_s, [poses_s, trans_s]], dthreshold=5.e-5,
+                                                     athreshold=self.angThred, w1=3.05, w2=1., times=10)
             if rev is not None:
                 r1.record(rstream); rev.append((r0, r1))
             refined = torch.cuda.Event()

@@ -240,3 +240,123 @@ def test_propagate_tmp_ps_grad_vs_the_references_own_run(golden):
         close(tp['lin0.weight'].grad[::41, ::9], g["g_tr_w0"], name="tr w0", **tol); close(tp['lin2.weight'].grad[::53, ::47], g["g_tr_w2"], name="tr w2", **tol)
         close(tp['lin4.bias'].grad, g["g_tr_b4"], name="tr b4", **tol); close(tp['lin4.weight'].grad[:, ::11], g["g_tr_w4"], name="tr w4", **tol)
         assert ds.conds[1].grad is None or float(ds.conds[1].grad.abs().max()) == 0.0
+
+
+def test_whole_iteration_vs_the_references_own_run(golden):
+    """The PRODUCT against the reference's own whole iteration (tests/golden/iteration.npz: OptimNetwork.forward + backward +
+    propagateTmpPsGrad of the reference run verbatim on CPU with the pytorch3d renderers replaced by the restated ones, every random
+    draw recorded -- oracle/gen_iteration_golden.py).  Same weights, data and draws: identical ray selection and seeds; the refiner's
+    output against the reference's (flags flip on single ulps, so it is compared on its own and the reference's is used after it);
+    every loss term, the total, the template SGD step, dL/dTmpPs and the gradients of the three networks, poses / translations /
+    codes and the learnable focal length / principal point / T."""
+    import numpy as np
+    from selfreconcode_amd import mlp_engine
+    from selfreconcode_amd.config import default_config
+    from selfreconcode_amd.model.network import getTmpSdf
+    from selfreconcode_amd.model.Deformer import MLPTranslator, LBSkinner, CompositeDeformer
+    from selfreconcode_amd.model.RenderNet import RenderingNetwork_view_norm
+    from selfreconcode_amd.model.optim_network import OptimNetwork
+    from selfreconcode_amd.utils import smpl_tmp_Apose
+    from selfreconcode_amd.utils.FindSurfacePs import OptimizeSurfacePs
+    g = golden("iteration")
+    Hh, Ww = int(g["HW"][0]), int(g["HW"][1])
+    sdf = getTmpSdf(DEV, 6, 0.6, 256)
+    sdf.load_state_dict(fx.sphere_sdf_params(7), strict=True)
+    tr = MLPTranslator(128, 6).to(DEV)
+    tr.load_state_dict(fx.det_params(fx.DEF_SPEC, 202, last_scale=0.05), strict=True)
+    rn = RenderingNetwork_view_norm(256, 'idr', 9, 3, [512, 512, 512, 512], True, multires_n=0, multires_v=4).to(DEV)
+    rn.load_state_dict(fx.det_params(fx.REND_SPEC, 303), strict=True)
+    skin = LBSkinner(fx.synthetic_lbs_volume((7, 11, 9)), fx.LBS_BMIN, fx.LBS_BMAX, fx.synthetic_joints(), np.array(fx.SMPL_PARENTS),
+                     init_pose=torch.from_numpy(smpl_tmp_Apose(1)), align_corners=False).to(DEV)
+    leaf = lambda t: t.to(DEV).clone().requires_grad_(True)
+
+    class Seq:                                                        # the accessors of dataset/dataset.py:76-81,117-147
+        frame_num = g["poses"].shape[0]
+        poses, trans, conds = leaf(g["poses"]), leaf(g["trans"]), [leaf(g["dcond"]), leaf(g["rcond"])]
+        camera_params = {'focal_length': leaf(g["focal"]), 'princeple_points': leaf(g["princ"]), 'world2cam_coord_trans': leaf(g["T"])}
+        R = g["R"].to(DEV)
+
+        def get_grad_parameters(self, idxs, device=None):
+            return self.poses[idxs], self.trans[idxs], self.conds[0][idxs], self.conds[1][idxs]
+
+        def get_camera_parameters(self, N, device=None):
+            c = self.camera_params
+            return (c['focal_length'].view(1, 2).expand(N, 2), c['princeple_points'].view(1, 2).expand(N, 2), self.R.view(1, 3, 3).expand(N, 3, 3),
+                    c['world2cam_coord_trans'].view(1, 3).expand(N, 3), Hh, Ww)
+
+        def get_batchframe_data(self, name, fids, batchsize):
+            data = getattr(self, name)
+            starts = (fids - batchsize // 2).clamp(min=0, max=self.frame_num - batchsize)
+            return data[starts.view(-1, 1) + torch.arange(0, batchsize, device=fids.device).view(1, batchsize)], fids - starts
+
+        def learnable_weights(self):
+            return [self.conds[0], self.conds[1]] + list(self.camera_params.values()) + [self.poses, self.trans]
+    ds = Seq()
+    net = OptimNetwork(sdf, CompositeDeformer([tr, skin]).to(DEV), None, None, rn, conf=default_config().get_config('loss_coarse')).to(DEV)
+    net.dataset = ds
+    net.dctnull = golden("misc")["dctnull"].to(DEV)
+    net.point_radius, net.angThred = float(g["radius"]), float(g["ang_thr"])
+    net.TmpVs, net.Tmpfs = g["V0"].to(DEV).clone().requires_grad_(True), g["faces"].long().to(DEV)
+    net.TmpOptimizer = torch.optim.SGD([net.TmpVs], lr=0.05, momentum=0.9)
+    net.forward_time = 1
+    fids = g["fids"].long().to(DEV)
+    datas = {'img': g["img"].to(DEV), 'mask': g["mask"].to(DEV), 'normal': g["normal"].to(DEV)}
+    rand = {k[5:]: v.to(DEV) for k, v in g.items() if k.startswith("rand_")}
+    SP = int(g["SP"])
+
+    # (1) the refiner on the reference's selected rays against the reference's refiner
+    with torch.no_grad():
+        poses, trans, d_cond, _ = [t.detach() for t in ds.get_grad_parameters(fids)]
+        p1, ok = OptimizeSurfacePs(g["cam_pos"].to(DEV), g["sel_rays"].to(DEV), g["sel_p0"].to(DEV).clone(), g["sel_bi"].long().to(DEV), sdf, RATIO,
+                                   net.deformer, [d_cond, [poses, trans]], dthreshold=5.e-5, athreshold=net.angThred, w1=3.05, w2=1., times=10)
+    ref_ok = g["sel_check"].bool()
+    assert float((ok.cpu() == ref_ok).float().mean()) > 0.95
+    both = ok.cpu() & ref_ok
+    assert int(both.sum()) > 50
+    dev_p = (p1.cpu()[both] - g["sel_p1"][both]).abs().amax(1)           # (rays that zigzag towards a threshold amplify 1-ulp differences)
+    assert float((dev_p < 2e-5).float().mean()) > 0.9 and float(dev_p.max()) < 5e-4, (float((dev_p < 2e-5).float().mean()), float(dev_p.max()))
+
+    # (2) the whole iteration with the reference's draws and the reference's refiner output
+    rand['refined'] = (g["sel_p1"], ref_ok)
+    mlp_engine.set_deferred_param_grads(True)
+    try:
+        dbg = {}
+        loss = net(datas, SP, RATIO, fids, rand=rand, debug=dbg)
+        assert torch.equal(dbg['batch_inds'].cpu(), g["sel_bi"].long()) and dbg['batch_inds'].numel() == int(g["ray_info"][0])
+        close(dbg['seeds'], g["sel_p0"], 1e-5, 1e-5, "seeds"); close(dbg['rays'], g["sel_rays"], 1e-5, 1e-5, "rays")
+        i = net.info
+        for k, v in (('mask_loss', i['pc_loss']['mask_loss']), ('defconst_loss', i['pc_loss']['defconst_loss']), ('grad_loss', i['grad_loss']),
+                     ('def_loss', i['def_loss']), ('dct_loss', i['dct_loss']), ('color_loss', i['color_loss']), ('normal_loss', i['normal_loss']),
+                     ('offset_loss', i['offset_loss'])):
+            close(v, g["L_" + k], 3e-4, 3e-4, k)
+        torch.testing.assert_close(i['pc_loss_sdf'].cpu().float(), g["L_pc_loss_sdf"].float(), rtol=2e-3, atol=2e-6)
+        close(loss, g["loss"], 3e-4, 3e-4, "total loss")
+        assert torch.equal(net.batch_inds.cpu(), g["bi"].long()) and torch.equal(net.row_inds.cpu(), g["rows"].long()) and torch.equal(net.col_inds.cpu(), g["cols"].long())
+        step, step_ref = net.TmpVs.detach().cpu() - g["V0"], g["V1"] - g["V0"]
+        close(step, step_ref, 2e-3, 3e-3, "template step")
+        loss.backward()
+        close(net.TmpPs.grad, g["g_TmpPs"], 2e-3, 3e-3, "dL/dTmpPs")
+        net.propagateTmpPsGrad(fids, RATIO)
+    finally:
+        mlp_engine.set_deferred_param_grads(False)
+    assert int(net.info['invInfo'][0]) == int(g["inv_info"][0]) and abs(int(net.info['invInfo'][1]) - int(g["inv_info"][1])) <= 1
+    sp, tp, rp = dict(sdf.named_parameters()), dict(tr.named_parameters()), dict(rn.named_parameters())
+    tol = dict(rtol=4e-3, frac=4e-3)
+    bad = []
+
+    def cmp(a, b, rtol=1e-3, frac=1e-3, name=""):        # collect every mismatch of the gradient block before failing
+        try:
+            close(a, b, rtol, frac, name)
+        except AssertionError as e:
+            bad.append(name + ": " + str(e).split("Greatest absolute difference:")[1].split("\n")[0].strip() + " max " + str(float(b.abs().max())))
+    cmp(ds.poses.grad, g["g_poses"], name="poses", **tol); cmp(ds.trans.grad, g["g_trans"], name="trans", **tol); cmp(ds.conds[0].grad, g["g_dcond"], name="dcond", **tol)
+    cmp(ds.camera_params['focal_length'].grad, g["g_focal"], name="focal", **tol); cmp(ds.camera_params['princeple_points'].grad, g["g_princ"], name="princ", **tol)
+    cmp(ds.camera_params['world2cam_coord_trans'].grad, g["g_T"], name="T", **tol)
+    cmp(sp['lin0.weight_v'].grad[::37, ::5], g["g_sdf_v0"], name="sdf v0", **tol); cmp(sp['lin4.weight_g'].grad, g["g_sdf_g4"], name="sdf g4", **tol)
+    cmp(sp['lin7.bias'].grad, g["g_sdf_b7"], name="sdf b7", **tol); cmp(sp['lin8.weight_v'].grad[::16, ::7], g["g_sdf_v8"], name="sdf v8", **tol)
+    cmp(tp['lin0.weight'].grad[::41, ::9], g["g_tr_w0"], name="tr w0", **tol); cmp(tp['lin2.weight'].grad[::53, ::47], g["g_tr_w2"], name="tr w2", **tol)
+    cmp(tp['lin4.bias'].grad, g["g_tr_b4"], name="tr b4", **tol); cmp(tp['lin4.weight'].grad[:, ::11], g["g_tr_w4"], name="tr w4", **tol)
+    cmp(rp['lin0.weight_v'].grad[::31, ::13], g["g_rn_v0"], name="render v0", **tol); cmp(rp['lin2.weight_g'].grad, g["g_rn_g2"], name="render g2", **tol)
+    cmp(rp['lin4.bias'].grad, g["g_rn_b4"], name="render b4", **tol)
+    assert ds.conds[1].grad is None or float(ds.conds[1].grad.abs().max()) == 0.0
+    assert not bad, bad

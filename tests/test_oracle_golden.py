@@ -228,3 +228,124 @@ def test_propagate_tmp_ps_grad_vs_the_references_own_run(golden):
     rel(tr["lin0.weight"].grad[::41, ::9], g["g_tr_w0"], name="tr w0"); rel(tr["lin2.weight"].grad[::53, ::47], g["g_tr_w2"], name="tr w2")
     rel(tr["lin4.bias"].grad, g["g_tr_b4"], name="tr b4"); rel(tr["lin4.weight"].grad[:, ::11], g["g_tr_w4"], name="tr w4")
     assert sc.rcond.grad is None                      # the render codes take no part in this pass
+
+
+def test_compute_tmp_pc_loss_vs_the_references_own_run(golden):
+    """a14 (template branch): oracle/iteration_oracle.py::pc_loss against tests/golden/pcloss.npz = OptimNetwork.computeTmpPcLoss of
+    the reference run verbatim on CPU (model/network.py:647-697) on silhouette masks from the restated point renderer: IoU and
+    deformation-consistency losses, the template SGD step, the gradients the inner backward deposits, |f(TmpVs)| and its backward."""
+    from oracle import iteration_oracle as ito
+    from oracle import raster_oracle as ro
+    from selfreconcode_amd.config import default_config
+    g = golden("pcloss")
+    conf = default_config().get_config('loss_coarse')
+    assert conf.get_float('pc_weight.weight') == 60. and conf.get_float('pc_weight.def_consistent.weight') == 0.6 and conf.get_float('pc_weight.def_consistent.c') == 0.01
+    leaf = lambda t: t.clone().requires_grad_(True)
+    sdf = {k: leaf(v) for k, v in fx.det_params(fx.SDF_SPEC, 101).items()}
+    tr = {k: leaf(v) for k, v in fx.det_params(fx.DEF_SPEC, 202).items()}
+    sc = ito.Scene(sdf, tr, None, _lbs_setup(golden("lbs")), leaf(g["poses"]), leaf(g["trans"]), leaf(g["dcond"]), None, None, conf, float(g["radius"]), 0.0)
+    fo = g["fids"].long()
+    H, W = int(g["HW"][0]), int(g["HW"][1])
+    TmpVs = g["V0"].clone().requires_grad_(True)
+    opt = torch.optim.SGD([TmpVs], lr=0.05, momentum=0.9)
+    defV = sc.deform(TmpVs[None].expand(2, -1, 3), sc.dcond[fo], sc.poses[fo], sc.trans[fo], None, RATIO)
+    masks, _ = ro.render_point_silhouette(defV, g["focal"], g["princ"], g["R"], g["T"], H, W, float(g["radius"]), 50)
+    close(masks, g["masks"], rtol=1e-4, atol=1e-5)
+    info = {}
+    out = ito.pc_loss(sc, TmpVs, opt, defV, sc.dcond[fo], sc.poses[fo], sc.trans[fo], masks, g["gt"], RATIO, info)
+    close(info['mask_loss'], g["mask_loss"], rtol=1e-5, atol=1e-6); close(info['defconst_loss'], g["defconst_loss"], rtol=1e-5, atol=1e-6)
+    close(info['pc_loss_sdf'], g["pc_loss_sdf"], rtol=1e-4, atol=1e-6); close(out, g["out"], rtol=1e-4, atol=1e-5)
+    step, step_ref = TmpVs.detach() - g["V0"], g["V1"] - g["V0"]
+    assert float(step_ref.abs().max()) > 1e-4
+    close(step, step_ref, rtol=1e-3, atol=1e-3 * float(step_ref.abs().max()))
+
+    def rel(a, b, tol=1e-3, name=""):
+        scale = float(b.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= tol * scale, (name, float((a - b).abs().max()), scale)
+    rel(tr["lin0.weight"].grad[::41, ::9], g["g_tr_w0"], name="tr w0"); rel(tr["lin2.weight"].grad[::53, ::47], g["g_tr_w2"], name="tr w2")
+    rel(tr["lin4.bias"].grad, g["g_tr_b4"], name="tr b4")
+    rel(sc.poses.grad, g["g_poses"], name="poses"); rel(sc.trans.grad, g["g_trans"], name="trans"); rel(sc.dcond.grad, g["g_dcond"], name="dcond")
+    out.backward()
+    rel(sdf["lin0.weight_v"].grad[::37, ::5], g["g_sdf_v0"], name="sdf v0"); rel(sdf["lin4.weight_g"].grad, g["g_sdf_g4"], name="sdf g4")
+    rel(sdf["lin7.bias"].grad, g["g_sdf_b7"], name="sdf b7"); rel(sdf["lin8.weight_v"].grad[:1, ::7], g["g_sdf_v8"], name="sdf v8")
+
+
+def _iteration_scene(g):
+    from oracle import iteration_oracle as ito
+    from selfreconcode_amd.config import default_config
+    conf = default_config().get_config('loss_coarse')
+    leaf = lambda t: t.clone().requires_grad_(True)
+    sdf = {k: leaf(v) for k, v in fx.sphere_sdf_params(7).items()}
+    tr = {k: leaf(v) for k, v in fx.det_params(fx.DEF_SPEC, 202, last_scale=0.05).items()}
+    rnd = {k: leaf(v) for k, v in fx.det_params(fx.REND_SPEC, 303).items()}
+    vol = fx.synthetic_lbs_volume((7, 11, 9))
+    import math
+    apose = torch.zeros(24, 3)
+    apose[1, 2], apose[2, 2] = 7. / 180. * math.pi, -7. / 180. * math.pi
+    apose[16, 2], apose[17, 2] = -55. / 180. * math.pi, 55. / 180. * math.pi
+    skin = dict(ws=vol, b_min=torch.tensor(fx.LBS_BMIN), b_max=torch.tensor(fx.LBS_BMAX), Js=fx.synthetic_joints(),
+                init_pose=orc.make_init_pose_inverse(apose, fx.synthetic_joints()))
+    cam = dict(focal=leaf(g["focal"]), princ=leaf(g["princ"]), R=g["R"], T=leaf(g["T"]), H=int(g["HW"][0]), W=int(g["HW"][1]))
+    sc = ito.Scene(sdf, tr, rnd, skin, leaf(g["poses"]), leaf(g["trans"]), leaf(g["dcond"]), leaf(g["rcond"]), cam, conf, float(g["radius"]), float(g["ang_thr"]))
+    return sc, conf
+
+
+def test_whole_iteration_vs_the_references_own_run(golden):
+    """The iteration oracle against the REFERENCE's whole iteration: tests/golden/iteration.npz = OptimNetwork.forward
+    (model/network.py:451-644) + backward + propagateTmpPsGrad (:702-814) run verbatim on CPU by oracle/gen_iteration_golden.py
+    (reference modules; the two pytorch3d renderers replaced by oracle/raster_oracle.py, CUDA extensions by their pinned
+    restatements) with every random draw recorded.  Same draws -> same ray selection and seeds, the refiner's output, every loss
+    term, the total, the moved template, dL/dTmpPs and the gradients of all three networks, the per-frame learnables and the
+    learnable camera tensors."""
+    from oracle import iteration_oracle as ito
+    g = golden("iteration")
+    sc, conf = _iteration_scene(g)
+    assert conf.get_float('dct_weight') == 2. and conf.get_float('color_weight') == 0.5 and conf.get_float('def_regu.c') == 0.5
+    fo = g["fids"].long()
+    N, SP, F = 2, int(g["SP"]), g["poses"].shape[0]
+    rand = {k[5:]: v for k, v in g.items() if k.startswith("rand_")}
+    datas = {'img': g["img"], 'mask': g["mask"], 'normal': g["normal"]}
+    bf = lambda f, n: ((f - n // 2).clamp(min=0, max=F - n)).view(-1, 1) + torch.arange(n).view(1, n)
+    dctnull = torch.stack([orc.dct_basis(k, 30) for k in range(10, 30)]) if hasattr(orc, "dct_basis") else golden("misc")["dctnull"]
+
+    # (1) the oracle's own selection + refiner against the reference's
+    TmpVs = g["V0"].clone().requires_grad_(True)
+    opt = torch.optim.SGD([TmpVs], lr=0.05, momentum=0.9)
+    tot, info, st = ito.forward(sc, TmpVs, g["faces"].long(), opt, datas, SP, RATIO, fo, rand, dctnull=dctnull, batchframe=bf)
+    assert info['rays'] == int(g["ray_info"][0]) and torch.equal(info['bi'], g["sel_bi"].long())
+    close(info['p0'], g["sel_p0"], rtol=1e-5, atol=1e-6)
+    agree = (info['check'] == g["sel_check"].bool()).float().mean()
+    assert float(agree) > 0.97, float(agree)                       # |f| < 5e-5 flips on single ulps
+    both = info['check'] & g["sel_check"].bool()
+    close(info['p1'][both], g["sel_p1"][both], rtol=1e-4, atol=2e-5)
+
+    # (2) everything after the refiner on the reference's rays
+    sc, _ = _iteration_scene(g)
+    TmpVs = g["V0"].clone().requires_grad_(True)
+    opt = torch.optim.SGD([TmpVs], lr=0.05, momentum=0.9)
+    tot, info, st = ito.forward(sc, TmpVs, g["faces"].long(), opt, datas, SP, RATIO, fo, rand, dctnull=dctnull, batchframe=bf,
+                                inject={'initTmpPs': g["sel_p1"], 'check': g["sel_check"].bool()})
+    for k in ('mask_loss', 'defconst_loss', 'grad_loss', 'def_loss', 'dct_loss', 'color_loss', 'normal_loss'):
+        close(info[k], g["L_" + k], rtol=2e-4, atol=2e-6)
+    torch.testing.assert_close(info['pc_loss_sdf'].float(), g["L_pc_loss_sdf"].float(), rtol=2e-3, atol=2e-6)
+    close(tot, g["loss"], rtol=2e-4, atol=1e-5)
+    step, step_ref = TmpVs.detach() - g["V0"], g["V1"] - g["V0"]
+    close(step, step_ref, rtol=1e-3, atol=2e-3 * float(step_ref.abs().max()))
+    assert torch.equal(st['bi'], g["bi"].long()) and torch.equal(st['rows'], g["rows"].long()) and torch.equal(st['cols'], g["cols"].long())
+    tot.backward()
+
+    def rel(a, b, tol=3e-3, name=""):
+        scale = float(b.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= tol * scale, (name, float((a - b).abs().max()), scale)
+    rel(st['TmpPs'].grad, g["g_TmpPs"], name="dL/dTmpPs")
+    n_sys, n_ok = ito.propagate(sc, st, fo, RATIO)
+    assert n_sys == int(g["inv_info"][0]) and abs(n_ok - int(g["inv_info"][1])) <= 1
+    rel(sc.poses.grad, g["g_poses"], name="poses"); rel(sc.trans.grad, g["g_trans"], name="trans"); rel(sc.dcond.grad, g["g_dcond"], name="dcond")
+    rel(sc.cam["focal"].grad, g["g_focal"], name="focal"); rel(sc.cam["princ"].grad, g["g_princ"], name="princ"); rel(sc.cam["T"].grad, g["g_T"], name="T")
+    rel(sc.sdf["lin0.weight_v"].grad[::37, ::5], g["g_sdf_v0"], name="sdf v0"); rel(sc.sdf["lin4.weight_g"].grad, g["g_sdf_g4"], name="sdf g4")
+    rel(sc.sdf["lin7.bias"].grad, g["g_sdf_b7"], name="sdf b7"); rel(sc.sdf["lin8.weight_v"].grad[::16, ::7], g["g_sdf_v8"], name="sdf v8")
+    rel(sc.tr["lin0.weight"].grad[::41, ::9], g["g_tr_w0"], name="tr w0"); rel(sc.tr["lin2.weight"].grad[::53, ::47], g["g_tr_w2"], name="tr w2")
+    rel(sc.tr["lin4.bias"].grad, g["g_tr_b4"], name="tr b4"); rel(sc.tr["lin4.weight"].grad[:, ::11], g["g_tr_w4"], name="tr w4")
+    rel(sc.rnd["lin0.weight_v"].grad[::31, ::13], g["g_rn_v0"], name="render v0"); rel(sc.rnd["lin2.weight_g"].grad, g["g_rn_g2"], name="render g2")
+    rel(sc.rnd["lin4.bias"].grad, g["g_rn_b4"], name="render b4")
+    assert sc.rcond.grad is None or float(sc.rcond.grad.abs().max()) == 0.0
