@@ -3,6 +3,11 @@ OptimNetwork.forward (model/network.py:451-644), computeTmpPcLoss (:647-697) and
 assembled from the row-level restatements of oracle/torch_oracle.py (each pinned to the reference's own modules through
 tests/golden) and oracle/raster_oracle.py (pytorch3d 0.4.0 restated, parity unpinned).
 
+PINNED as a whole: tests/test_oracle_golden.py holds `forward` + `propagate` to tests/golden/iteration.npz and `pc_loss` to
+tests/golden/pcloss.npz -- the reference's own OptimNetwork.forward / backward / propagateTmpPsGrad / computeTmpPcLoss run verbatim
+on CPU by oracle/gen_iteration_golden.py and oracle/gen_golden.py (reference modules; only the two pytorch3d renderers are the
+restated ones, so the rasterisers remain the unpinned part).
+
 Random draws are passed in (`rand`), exactly the tensors the product's `forward(..., rand=...)` takes, so both sides see
 the same numbers (SURVEY.md 7 "Randomness").  Everything runs in the dtype of the parameters handed in (float32 or float64).
 """
