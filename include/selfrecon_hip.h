@@ -27,6 +27,7 @@ extern "C" {
 
 int sr_abi_version(void);            /* bumps when a signature below changes */
 const char* sr_build_arch(void);     /* "gfx950" */
+const char* sr_build_digest(void);   /* sha256 of the sources the library was built from (selfreconcode_amd/build.py) */
 
 /* ---------------------------------------------------------------- FastMinv (a7)
  * Replaces FastMinv/M3x3Inv.cpp:12-38 Fast3x3Minv -> Matrix3x3InvKernels.cu:22-61 and

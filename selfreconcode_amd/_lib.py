@@ -113,7 +113,10 @@ if "SELFRECON_HIP_LIB" in os.environ:
 else:
     from .build import is_stale, build_lib
     if is_stale():                                # sources changed since the .so was linked (or no .so yet): kernels and the ctypes
-        build_lib(verbose=False)                  # structs below must come from the same tree -- rebuild (hipcc) or fail loudly
+        try:                                      # structs below must come from the same tree -- rebuild (one process builds under an
+            build_lib(verbose=False)              # flock, the others wait; atomic publish) or fail loudly
+        except RuntimeError as e:
+            raise ImportError(str(e)) from e
 if not os.path.isfile(LIB):
     raise ImportError(f"{LIB} not found: run `python -m selfreconcode_amd.build` (hipcc --offload-arch=gfx950). "
                       "There is no CPU fallback for the HIP hot path.")
@@ -205,6 +208,7 @@ for _name, _args in SIGNATURES.items():
     _fn[_name] = _f
 _lib.sr_abi_version.restype = _int
 _lib.sr_build_arch.restype = ctypes.c_char_p
+_lib.sr_build_digest.restype = ctypes.c_char_p
 
 
 def abi_version():
@@ -213,6 +217,10 @@ def abi_version():
 
 def build_arch():
     return _lib.sr_build_arch().decode()
+
+
+def build_digest():
+    return _lib.sr_build_digest().decode()
 
 
 def raw(name):

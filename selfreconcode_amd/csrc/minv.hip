@@ -104,6 +104,13 @@ int minv_bwd(const T* grads, const T* invs, T* outs, int64_t n, void* stream) {
 extern "C" {
 int sr_abi_version(void) { return 1; }
 const char* sr_build_arch(void) { return "gfx950"; }
+// digest of the sources this library was built from (selfreconcode_amd/build.py passes it; the marker string is what build.py
+// looks for inside the .so to decide whether the library matches the tree -- no side file needed)
+#ifndef SR_BUILD_DIGEST_STR
+#define SR_BUILD_DIGEST_STR "unknown"
+#endif
+__attribute__((used)) const char sr_build_digest_marker[] = "SR_BUILD_DIGEST=" SR_BUILD_DIGEST_STR;
+const char* sr_build_digest(void) { return sr_build_digest_marker + 16; }
 int sr_minv3x3_fwd_f32(const float* ms, float* invs, uint8_t* checks, int64_t n, void* s) { return minv_fwd<float>(ms, invs, checks, n, s); }
 int sr_minv3x3_fwd_f64(const double* ms, double* invs, uint8_t* checks, int64_t n, void* s) { return minv_fwd<double>(ms, invs, checks, n, s); }
 int sr_minv3x3_bwd_f32(const float* g, const float* i, float* o, int64_t n, void* s) { return minv_bwd<float>(g, i, o, n, s); }

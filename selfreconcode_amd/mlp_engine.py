@@ -542,8 +542,9 @@ def refresh_packs(lins):
     """Brings the pack entries of `lins` (the nn.Linear layers of one network) up to date with their parameters: entries that exist
     and are stale (the optimizer stepped) are re-filled IN PLACE by one launch; entries that do not exist yet are left to the
     per-layer torch path of pack_linear (first call only).  In-place refresh keeps every pointer (W, WT, gradient buffers)
-    stable across optimizer steps.  (A graph built on the old values must be back-propagated before the optimizer step that
-    precedes this refresh -- as every training loop does; the kernel writes the buffers behind torch's version counters.)"""
+    stable across optimizer steps.  A graph built on the old values must be back-propagated before the optimizer step that
+    precedes this refresh -- as every training loop does; one that is not gets autograd's in-place error (the version counters of
+    the refreshed buffers are bumped after the kernel), never stale weights."""
     if not FUSED_PACK or not lins:
         return
     first = lins[0].weight_v if hasattr(lins[0], "weight_g") else lins[0].weight
@@ -580,6 +581,11 @@ def refresh_packs(lins):
             _lib.call("sr_pack_weights", ctypes.byref(t), _lib.stream_of(chunk[0][1]))
         for e, v, g, sig in chunk:
             e["sig"] = sig
+        # The kernel wrote W / WT / norms behind torch's version counters.  Bump them (host-only, no launch): a graph that saved the
+        # OLD values -- a retained graph, gradient accumulation over two forwards with an optimizer step in between, a delayed
+        # backward -- now raises autograd's "modified by an inplace operation" error instead of silently back-propagating with
+        # the new weights.
+        torch.autograd.graph.increment_version([t for e, _, _, _ in chunk for t in (e["W"], e["WT"], e["norms"]) if t is not None])
 
 
 PLAIN_PACKS = os.environ.get("SR_PLAIN_PACKS", "1") != "0"
@@ -594,8 +600,12 @@ def pack_linear(lin):
         wn = hasattr(lin, "weight_g")
         v = lin.weight_v if wn else lin.weight
         e = _PACK_CACHE.get(id(v))
-        if e is not None and e["sig"] == (_sig(v, lin.weight_g) if wn else _sig(v)) and "src" in e:
-            e["bias_param"] = lin.bias
+        b = lin.bias
+        # (a layer whose bias is frozen or not a leaf has no deferred sink -- _deferred_sink keys the buffers on the bias -- so its
+        # weight must keep an autograd node, or its gradient would be dropped without an error: take the autograd pack below)
+        if (e is not None and e["sig"] == (_sig(v, lin.weight_g) if wn else _sig(v)) and "src" in e
+                and b is not None and b.is_leaf and b.requires_grad):
+            e["bias_param"] = b
             return e["W"]
     if hasattr(lin, "weight_g"):
         W = PackWeightNorm.apply(lin.weight_v, lin.weight_g)

@@ -64,7 +64,16 @@ class PointsSilhouette(Function):
         return gxy, None, None, None, None, None
 
 
+def _require_square(H, W, what):
+    # pytorch3d 0.4.0 rescales the NDC range of the longer side of a non-square image; the kernels (pix_to_ndc = 1 - (2 i + 1) / S on
+    # both axes) and the reference's own camera class implement the square convention only -- refuse instead of rendering something
+    # the reference pipeline would not
+    if int(H) != int(W):
+        raise RuntimeError(f"{what}: non-square images ({H} x {W}) are not supported (pytorch3d 0.4.0 rescales NDC for them; see DESIGN.md 8)")
+
+
 def points_silhouette(xy_ndc, z, H, W, radius, points_per_pixel=50):
+    _require_square(H, W, "points_silhouette")
     return PointsSilhouette.apply(xy_ndc, z, H, W, radius, points_per_pixel)
 
 
@@ -79,6 +88,7 @@ def rasterize_meshes(xy_ndc, z, faces, H, W):
     """No-grad hard rasterisation of N images of one mesh topology with the semantics of the reference's MeshRasterizer
     settings (model/network.py:877-892; see sr_rasterize_meshes)."""
     _lib.require_gpu(xy_ndc)
+    _require_square(H, W, "rasterize_meshes")
     xy = xy_ndc.detach().contiguous().float(); z = z.detach().contiguous().float(); faces = faces.contiguous()
     N, V = xy.shape[0], xy.shape[1]
     dev = xy.device

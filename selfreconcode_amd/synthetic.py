@@ -141,6 +141,35 @@ def sphere_sdf_params(seed=7, bias=0.6, multires=6, feat=256):
     return sd
 
 
+def cube_sphere(n):
+    """Closed triangle mesh of the unit sphere from a cube with n x n cells per face: V = 6 n^2 + 2 vertices, F = 12 n^2 faces,
+    outward winding.  A pure function of n (float64 numpy, exact integer lattice) -- the template of the full-size parity
+    fixtures (n = 119 -> 84 968 vertices, the size marching cubes gives the coarse stage; n = 170 -> 173 402, fine stage)."""
+    g = np.arange(n + 1)
+    u, v = np.meshgrid(g, g, indexing="ij")
+    z0, zn = np.zeros_like(u), np.full_like(u, n)
+    # (lattice coordinates, and whether (du x dv) points outward) for the six faces
+    sides = [(np.stack([z0, u, v], -1), False), (np.stack([zn, u, v], -1), True), (np.stack([u, z0, v], -1), True),
+             (np.stack([u, zn, v], -1), False), (np.stack([u, v, z0], -1), False), (np.stack([u, v, zn], -1), True)]
+    keys, quads = [], []
+    for lat, outward in sides:
+        k = (lat[..., 0] * (n + 1) + lat[..., 1]) * (n + 1) + lat[..., 2]
+        base = len(keys) * (n + 1) ** 2
+        idx = base + np.arange((n + 1) ** 2).reshape(n + 1, n + 1)
+        a, b, c, d = idx[:-1, :-1], idx[1:, :-1], idx[1:, 1:], idx[:-1, 1:]
+        tri = np.stack([np.stack([a, b, c], -1), np.stack([a, c, d], -1)], 2).reshape(-1, 3)
+        quads.append(tri if outward else tri[:, ::-1])
+        keys.append(k.reshape(-1))
+    keys = np.concatenate(keys)
+    uniq, inv = np.unique(keys, return_inverse=True)
+    faces = inv[np.concatenate(quads)]
+    lat = np.stack([uniq // (n + 1) ** 2, (uniq // (n + 1)) % (n + 1), uniq % (n + 1)], -1).astype(np.float64)
+    p = lat * (2.0 / n) - 1.0
+    p = np.tan(p * (np.pi / 4.0))                              # equal-angle warp: cells of nearly equal size on the sphere
+    dirs = p / np.linalg.norm(p, axis=1, keepdims=True)
+    return torch.from_numpy(dirs).float(), torch.from_numpy(faces.astype(np.int64))
+
+
 # ------------------------------------------------------------------------------------------------
 # Synthetic sequence + scene builder (SURVEY.md 8(d) cfg2/cfg3): the tensor contract of
 # dataset/dataset.py (poses / trans / per-frame codes as dense learnable tensors, one camera),

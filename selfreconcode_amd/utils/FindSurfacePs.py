@@ -162,7 +162,7 @@ DEVICE_DRIVEN = True
 CHAIN_PERSISTENT = os.environ.get("SR_CHAIN_PERSISTENT", "0") == "1"   # whole chain in one launch behind device-wide barriers
                                                                                    # (56 launches per call instead of ~230, but slower: see DESIGN.md)
 CHAIN_POLL_MODE = int(os.environ.get("SR_CHAIN_POLL", "0"))     # tuning switch of the chain kernel's device-wide barrier
-_WORKSPACES = {}     # (device, capacity) -> _RefinerWorkspace
+_WORKSPACES = {}     # (device, stream handle) -> _RefinerWorkspace (grow-only)
 _ERROR_WATCH = {}    # device -> (pinned int32, event) of the previous call's barrier-failure flag
 
 
@@ -245,12 +245,15 @@ def _optimize_device_driven(ev, cam, rays, initTmpPs, batch_inds, dthreshold, at
         watch[1].synchronize()
         if int(watch[0][0]) != 0:
             raise _lib.SrError("sr_mlp_chain: the device-wide barrier of the previous refiner call gave up (persistent grid not resident)")
-    cap = (P + 1023) // 1024 * 1024
-    key = (dev, cap)
+    # ONE grow-only workspace per (device, stream): capacity = next power of two of the largest ray count seen (the Bernoulli ray
+    # selection changes P every call; 57 KB per row).  It is allocated and only ever used with its stream current, so the caching
+    # allocator may hand a replaced workspace's blocks to that stream again without any cross-stream hazard.
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     ws = _WORKSPACES.get(key)
-    if ws is None or ws.times_cap < times:
-        for k in [k for k in _WORKSPACES if k[0] == dev and k[1] != cap and len(_WORKSPACES) > 3]:
-            del _WORKSPACES[k]
+    if ws is None or ws.cap < P or ws.times_cap < times:
+        cap = max(1024, 1 << max(P - 1, 0).bit_length(), 0 if ws is None else ws.cap)
+        ws = None
+        _WORKSPACES.pop(key, None)
         ws = _WORKSPACES[key] = _RefinerWorkspace(dev, cap, ev, max(times, 30))
     x0 = initTmpPs.contiguous().float()
     bi = batch_inds.contiguous()

@@ -27,5 +27,5 @@ def pytest_collection_modifyitems(config, items):
 def golden():
     def load(name):
         d = np.load(os.path.join(GOLDEN, name + ".npz"))
-        return {k: torch.from_numpy(np.asarray(d[k])) for k in d.files}
+        return {k: torch.from_numpy(np.asarray(d[k])) for k in d.files if d[k].dtype.kind in 'biuf'}
     return load

@@ -28,9 +28,11 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_python_binding_covers_the_header():
     from selfreconcode_amd import _lib
-    decl = set(_declared()) - {"sr_abi_version", "sr_build_arch"}
+    decl = set(_declared()) - {"sr_abi_version", "sr_build_arch", "sr_build_digest"}
     assert decl == set(_lib.SIGNATURES), decl ^ set(_lib.SIGNATURES)
     assert _lib.build_arch() == "gfx950" and _lib.abi_version() >= 1
+    from selfreconcode_amd import build
+    assert _lib.build_digest() == build._digest() == build.embedded_digest()      # the loaded library is the one these sources describe
 
 
 def test_no_cpu_fallback():
