@@ -1,8 +1,16 @@
 #!/usr/bin/env python
 """bench.py -- `train.py`-equivalent iterations/s of the SelfRecon SDF-optimisation hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--stage coarse|fine] [--lr LR] [--no-fine]
+    python bench.py --gpus N --steps K --warmup W [--stage coarse|fine] [--lr LR] [--no-fine] [--scaling weak|strong] [--frames-per-gpu F]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+(a plain `python bench.py --gpus N` with N > 1 and no launcher environment re-executes itself through torch.distributed.run, one rank
+per GPU -- all ranks on device 0 if the box has fewer than N GPUs, which is a functional run, not a measurement)
+
+Scaling modes (the path shards over FRAMES, no data-path collective besides the gradient all-reduce):
+  weak   (default)  every rank optimises `--frames-per-gpu` frames per step (default: the stage's batch size, 3 coarse / 1 fine);
+                    `--frames-per-gpu 1` at N = 8 is BASELINE.json configs[2] (8 frames, one per GPU);
+  strong            `--global-frames` frames per step (default 8 = configs[2]) are split over the ranks: 8 / N frames each.
+`value` counts reference iterations: frames processed per second / the stage's batch size (3 coarse, 1 fine), whole job.
 
 One "step" = one full training iteration of BASELINE.json configs[1] (female-3-casual-like, 540x540): template deformation +
 point-silhouette mask loss + template SGD step, mesh rasterisation + ray seeding + Newton refiner, eikonal / offset / deformation-
@@ -45,12 +53,21 @@ sys.path.insert(0, ROOT)
 STAGES = {"coarse": dict(frames=3, rays=2048), "fine": dict(frames=1, rays=6144)}
 
 
+def frames_per_rank(stage, args, world):
+    """Frames one rank optimises per step (see the scaling modes in the module docstring)."""
+    if args.scaling == "strong":
+        if args.global_frames % world:
+            raise SystemExit(f"--scaling strong: --global-frames {args.global_frames} is not divisible by {world} ranks")
+        return args.global_frames // world
+    return args.frames_per_gpu or STAGES[stage]["frames"]
+
+
 def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_low, gemm_events):
     from selfreconcode_amd import dist as srdist
     from selfreconcode_amd import mlp_engine
     from selfreconcode_amd.synthetic import build_synthetic_scene
-    FR, RAYS = STAGES[stage]["frames"], STAGES[stage]["rays"]
-    net, ds, conf = build_synthetic_scene(device=device, frame_num=64 if world <= 8 else 8 * world, stage=stage, consistent_masks=False)
+    FR, RAYS = frames_per_rank(stage, args, world), STAGES[stage]["rays"]
+    net, ds, conf = build_synthetic_scene(device=device, frame_num=max(64, 2 * FR * world), stage=stage, consistent_masks=False)
     params = [p for p in net.parameters() if p.requires_grad]
     net.refiner_stream = args.refiner_stream
     from selfreconcode_amd.utils import FindSurfacePs as _fsp
@@ -163,12 +180,32 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
     return rec
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-execute through torch.distributed.run, one rank per GPU, same arguments."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() < n:                       # functional run of the N-rank path on a smaller box (not a measurement)
+        env["SR_ALL_RANKS_ON_DEVICE0"] = "1"
+        env.setdefault("SR_DIST_BACKEND", "gloo")           # RCCL refuses two ranks on one device
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--stage", choices=list(STAGES), default="coarse")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: fixed frames per GPU; strong: --global-frames split over the GPUs")
+    ap.add_argument("--frames-per-gpu", type=int, default=0, help="weak scaling: frames per rank and step (default: the stage's batch size; 1 at N=8 = configs[2])")
+    ap.add_argument("--global-frames", type=int, default=8, help="strong scaling: frames per step over all ranks (8 = configs[2])")
     ap.add_argument("--lr", type=float, default=1e-4 * 0.333 ** 3, help="Adam learning rate of the timed region (the settle phase runs at config's 1e-4)")
     ap.add_argument("--settle", type=int, default=120, help="untimed iterations at lr 1e-4 before the timed region")
     ap.add_argument("--settle-low", type=int, default=40, help="untimed iterations at --lr before warm-up")
@@ -182,9 +219,12 @@ def main():
     ap.add_argument("--shape-log", default=None, help="write the per-(M,N,K) GEMM launch table (events) to this JSON file")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     from selfreconcode_amd import dist as srdist
     rank, world, device = srdist.init_from_env("cuda")
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
 
     main_rec = run_stage(args.stage, args, rank, world, device, args.steps, args.warmup, args.settle, args.settle_low, not args.no_gemm_events)
     net = main_rec.pop("net")
@@ -208,7 +248,7 @@ def main():
     gc.collect(); torch.cuda.empty_cache()
 
     fine_rec = None
-    if world == 1 and args.stage == "coarse" and not args.no_fine:
+    if world == 1 and args.stage == "coarse" and not args.no_fine and args.scaling == "weak" and not args.frames_per_gpu:
         fine_rec = run_stage("fine", args, rank, world, device, args.steps, args.warmup, max(args.settle // 2, 0), args.settle_low, False)
         for k in ("net", "prof", "shapes", "elapsed"):
             fine_rec.pop(k, None)
@@ -216,16 +256,24 @@ def main():
 
     if rank != 0:
         return
-    FR, RAYS = STAGES[args.stage]["frames"], STAGES[args.stage]["rays"]
+    FR, RAYS = main_rec["frames_per_gpu"], STAGES[args.stage]["rays"]
+    FR_REF = STAGES[args.stage]["frames"]                      # frames of one reference iteration of this stage (config.conf batch_size)
+    shared = os.environ.get("SR_ALL_RANKS_ON_DEVICE0") == "1" and world > 1
     flops_step = (prof.get("flops_total", 0.0) + prof.get("flops_total_tn", 0.0)) / max(args.steps, 1)      # every layer GEMM: forward, backward-data, weight-gradient, refiner chains
     out = {
-        "metric": f"train.py-equivalent iterations/sec (540x540, {RAYS} rays/frame x {FR} frame{'s' if FR > 1 else ''} per GPU)",
-        "value": round(args.steps * world / elapsed, 4), "unit": "iterations/s",
+        "metric": f"train.py-equivalent iterations/sec (540x540, {RAYS} rays/frame x {FR} frame{'s' if FR > 1 else ''} per GPU; Adam lr {args.lr:.3g} = the "
+                  f"MultiStepLR value of epochs 80-130 of config.conf's 1e-4 schedule, see regime_lr_config for lr 1e-4)",
+        "value": round(args.steps * world * FR / FR_REF / elapsed, 4), "unit": "iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_rec["ms_per_step"],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[1]: female-3-casual-like 540x540, {args.stage} stage, {FR} frame(s) x {RAYS} rays per rank, full iteration "
                                "(template deform + K=50 point-silhouette mask loss + template SGD, mesh rasteriser + seeds + Newton refiner, "
                                "eikonal/offset/def-regu/DCT/colour/normal, backward, implicit-grad propagation, Adam, one remesh in the timed window)",
+                   "scaling_mode": (f"strong: {args.global_frames} frames per step split over {world} rank(s)" if args.scaling == "strong" else
+                                    f"weak: {FR} frame(s) per rank and step, {FR * world} per step over {world} rank(s)")
+                                   + ("; ALL RANKS SHARE DEVICE 0 (functional run, not a measurement)" if shared else ""),
+                   "frames_per_step_all_ranks": FR * world, "frames_per_s": round(args.steps * world * FR / elapsed, 3),
+                   "value_definition": f"frames per second / {FR_REF} (the frames of one reference iteration of the {args.stage} stage), whole job",
                    "stage": args.stage, "frames_per_gpu": FR, "rays_per_frame": RAYS, "image": main_rec["image"], "template_vertices": V,
                    "rays_per_iter": main_rec["rays_per_iter"], "rays_converged_frac": main_rec["rays_converged_frac"],
                    "observations": "uniform noise" if args.noise_observations else "rendered from the scene (render_frames), re-rendered after the settle phase",

@@ -196,14 +196,18 @@ typedef struct {
 } sr_lbs_args;
 int sr_lbs_fwd(const sr_lbs_args* host_args, void* stream);
 /* Reverse sweep of sr_lbs_fwd for a cotangent ybar [P,3] (replaces the autograd backward of the K3/K4 sampler +
- * per-frame blend, model/Deformer.py:207-233): pbar = (dy/dp)^T ybar, Abar [nframes,24,12] += w_j ybar (x) [p;1],
- * transbar [nframes,3] += ybar.  Abar / transbar are accumulated (zero-fill first); each output is nullable. */
-int sr_lbs_bwd(const sr_lbs_args* host_args, const float* ybar, float* pbar, float* Abar, float* transbar, void* stream);
+ * per-frame blend, model/Deformer.py:207-233): pbar = (dy/dp)^T ybar, Abar [nframes,24,12] = sum w_j ybar (x) [p;1],
+ * transbar [nframes,3] = sum ybar.  Abar / transbar are WRITTEN (no zero fill); each output is nullable.  The per-frame sums are
+ * deterministic (segmented wave reductions, per-workgroup partials in `partials`, folded in double precision in a fixed order):
+ * bit-reproducible run to run.  `partials`: sr_lbs_bwd_workspace_floats(P, nframes) floats of scratch. */
+int64_t sr_lbs_bwd_workspace_floats(int64_t P, int32_t nframes);
+int sr_lbs_bwd(const sr_lbs_args* host_args, const float* ybar, float* pbar, float* Abar, float* transbar, float* partials, void* stream);
 /* Reverse sweep of sr_lbs_fwd WITH its Jacobian output: cotangents ybar [P,3] (nullable) and Jbar [P,3,3] of (y, jac) ->
- * pbar (includes the mixed second derivatives of the trilinear sampler), Abar, transbar (accumulated as in sr_lbs_bwd).
+ * pbar (includes the mixed second derivatives of the trilinear sampler), Abar, transbar (written as in sr_lbs_bwd; same scratch).
  * Backward of the value + Jacobian form of the deformer that replaces compute_Jacobian's three reverse passes with
  * create_graph (utils/utils.py:106-120) in the colour / normal branch and in propagateTmpPsGrad. */
-int sr_lbs_jac_bwd(const sr_lbs_args* host_args, const float* ybar, const float* Jbar, float* pbar, float* Abar, float* transbar, void* stream);
+int sr_lbs_jac_bwd(const sr_lbs_args* host_args, const float* ybar, const float* Jbar, float* pbar, float* Abar, float* transbar, float* partials,
+                   void* stream);
 
 /* SMPL kinematic chain of LBSkinner.forward / posedSkeleton (model/Deformer.py:144-203, smpl_pytorch/util.py:35-78):
  * poses [B,24,3] axis-angle (device) -> G [B,24,4,4] posed chain and A = G * init_pose [B,24,4,4].

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- ONE WHOLE training iteration of the reference AT THE SIZE BASELINE.json configs[1] IS QUOTED ON,
 run verbatim on CPU and frozen into tests/golden/iteration_full_{coarse,fine}.npz (build container only: needs /root/reference):
 
-    python oracle/gen_fullsize_golden.py [coarse|fine|both] [--time]
+    python oracle/gen_fullsize_golden.py [coarse|fine|both] [--time] [--no-golden]
 
 540 x 540 images, the real 65 x 225 x 129 skinning-weight volume, a template of 84 968 vertices / 169 932 faces (coarse stage:
 3 frames x 2048 rays, config.conf:28-34) or 173 402 vertices (fine stage: 1 frame x 6144 rays, loss_fine, config.conf:39-48,113).
@@ -15,8 +15,10 @@ propagateTmpPsGrad on the reference's own modules; pytorch3d renderers -> oracle
     forward runs), so the product gets the same numbers through `rand=`.
 Stored: ray selection, seeds, the refiner's output, every loss term, the total, the template step (strided), dL/dTmpPs, whole
 per-frame / camera gradients and -- for every parameter of the three networks -- its L2 norm, two fixed random projections and a
-strided slice.  `--time` additionally writes profiles/r03_cpu_reference.json: the reference's own modules timed on this container's
-cores at full size (warm-up = the golden run, then median of 3), the `cpu_baseline` of kind "reference" that bench.py reports.
+strided slice, and f at the moved template vertices.  The fixture run evaluates the reference's modules in FLOAT64 on the same
+(float32-representable) inputs -- see build() -- so the product is held to the reference's algorithm, not to one float32 rounding of it.
+`--time` additionally writes profiles/r03_cpu_reference.json: the reference's own modules in float32, as they run, timed on this
+container's cores at full size (warm-up 1, then median of 3) -- the `cpu_baseline` of kind "reference" that bench.py reports.
 """
 import json
 import os
@@ -66,10 +68,15 @@ def mask_image(N, H, W):
     return m[None].expand(N, H, W).contiguous()
 
 
-def build(stage, H=540, W=540, lbs_shape=(65, 225, 129), F=40, n_cube=None):
+def build(stage, H=540, W=540, lbs_shape=(65, 225, 129), F=40, n_cube=None, dtype=torch.float32):
+    """`dtype`: float32 = the reference as it runs (timing); float64 = the same modules, same float32-representable inputs, evaluated in
+    double (torch's default dtype is switched so that every tensor the reference creates on the way is double too): the fixture then
+    holds the reference's algorithm WITHOUT its own float32 rounding noise -- at this size several gradients are sums over 10^5
+    points with heavy cancellation, and two float32 evaluations that differ only in summation order disagree by up to 1e-2 there."""
     cfg = STAGES[stage]
     N = cfg["N"]
     n_cube = n_cube or cfg["n_cube"]
+    torch.set_default_dtype(dtype)
     sdf = ref.network.getTmpSdf("cpu", 6, 0.6, 256)
     sdf.load_state_dict(fx.sphere_sdf_params(7), strict=True)
     tr = ref.Deformer.MLPTranslator(128, 6)
@@ -79,17 +86,19 @@ def build(stage, H=540, W=540, lbs_shape=(65, 225, 129), F=40, n_cube=None):
     comp = ref.Deformer.CompositeDeformer([tr, skin])
     rn = ref.RenderNet.RenderingNetwork_view_norm(256, 'idr', 9, 3, [512, 512, 512, 512], True, multires_n=0, multires_v=4)
     rn.load_state_dict(fx.det_params(fx.REND_SPEC, 303), strict=True)
+    for m in (sdf, comp, rn):
+        m.to(dtype)
 
     class Seq:
         frame_num = F
         video_segmented_index = []
 
         def __init__(self):
-            leaf = lambda t: t.clone().requires_grad_(True)
+            leaf = lambda t: t.to(dtype).clone().requires_grad_(True)
             self.poses = leaf(fx.det_tensor((F, 24, 3), 91, 0.12)); self.trans = leaf(fx.det_tensor((F, 3), 92, 0.04))
             self.conds = [leaf(fx.det_tensor((F, 128), 93, 0.1)), leaf(fx.det_tensor((F, 256), 94, 0.1))]
             self.focal = leaf(torch.tensor([1.2 * W, 1.2 * W])); self.princ = leaf(torch.tensor([W / 2.0, H / 2.0])); self.T = leaf(torch.tensor([0., 0.1, 2.4]))
-            self.R = orc.quat2mat(torch.tensor([[0., 0., 1., 0.]]))
+            self.R = orc.quat2mat(torch.tensor([[0., 0., 1., 0.]])).to(dtype)
 
         def get_grad_parameters(self, idxs, device):
             return self.poses[idxs], self.trans[idxs], self.conds[0][idxs], self.conds[1][idxs]
@@ -106,9 +115,9 @@ def build(stage, H=540, W=540, lbs_shape=(65, 225, 129), F=40, n_cube=None):
     with torch.no_grad():
         r = torch.full((dirs.shape[0], 1), 0.6)
         for _ in range(30):
-            r = r - torch.cat([sdf(part * rp, 1.0)[:, 0:1] for part, rp in zip(torch.split(dirs, 20000), torch.split(r, 20000))])
+            r = r - torch.cat([sdf(part.to(dtype) * rp, 1.0)[:, 0:1] for part, rp in zip(torch.split(dirs, 20000), torch.split(r, 20000))])
     q = torch.round((r - 0.6) * 65536.).clamp(-32768, 32767).to(torch.int16)
-    V0 = template_from_q(dirs, q)
+    V0 = template_from_q(dirs, q)                  # float32 arithmetic whatever `dtype` is: the product builds the same template
     net = object.__new__(ref.network.OptimNetwork)
     torch.nn.Module.__init__(net)
     net.conf = gi.DictConf(cfg["conf"])
@@ -116,24 +125,25 @@ def build(stage, H=540, W=540, lbs_shape=(65, 225, 129), F=40, n_cube=None):
     mr, pr = gi.MaskRender(H, W, faces), gi.PcRender(H, W, cfg["radius"])
     net.maskRender, net.pcRender = mr, pr
     net.engine = None
-    net.TmpVs, net.Tmpfs = V0.clone().requires_grad_(True), faces
+    net.TmpVs, net.Tmpfs = V0.to(dtype).clone().requires_grad_(True), faces
     net.TmpOptimizer = torch.optim.SGD([net.TmpVs], lr=0.05, momentum=0.9)
     net.forward_time, net.remesh_intersect, net.remesh_time = 1, 30, 0.
     net.next_conf = net.next_train_conf = None
     net.draw, net.enable_mesh_color, net.sdfShrinkRadius = False, True, 0.0
-    net.dctnull = ref.rutils.DCTNullSpace(10, 30)
+    net.dctnull = ref.rutils.DCTNullSpace(10, 30).to(dtype)
     cam0 = ref.network.RectifiedPerspectiveCameras(*ds.get_camera_parameters(N, 'cpu')[:4], image_size=[(W, H)])
     net.angThred = cam0.angThreshold(0.5)
     fids = torch.tensor(cfg["fids"])
     datas = {'img': fx.det_tensor((N, H, W, 3), 95, 1.0), 'mask': mask_image(N, H, W), 'normal': fx.det_tensor((N, H, W, 3), 96, 1.0)}
     datas['normal'][:, ::5] = 0.
+    datas = {k: v.to(dtype) for k, v in datas.items()}
     return net, ds, datas, fids, q, V0, faces
 
 
 def template_from_q(dirs, q):
     """The template both sides build: float32 products / sums only (IEEE-exact, identical everywhere)."""
-    r = 0.6 + q.float() / 65536.
-    return dirs * r + fx.det_tensor((dirs.shape[0], 3), 97, 0.004)
+    r = 0.6 + q.to(torch.float32) / 65536.
+    return dirs.to(torch.float32) * r + fx.det_tensor((dirs.shape[0], 3), 97, 0.004)
 
 
 class DetDraws:
@@ -145,11 +155,11 @@ class DetDraws:
     def rand(self, *size, **k):
         shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
         self.calls.append(('rand', shape))
-        return fx.det_tensor(shape, DRAW_SEED0 + len(self.calls) - 1, 0.5) + 0.5
+        return (fx.det_tensor(shape, DRAW_SEED0 + len(self.calls) - 1, 0.5) + 0.5).to(torch.get_default_dtype())      # (float32 values)
 
     def randn_like(self, x, **k):
         self.calls.append(('randn_like', tuple(x.shape)))
-        return fx.det_normal(tuple(x.shape), DRAW_SEED0 + len(self.calls) - 1)
+        return fx.det_normal(tuple(x.shape), DRAW_SEED0 + len(self.calls) - 1).to(x.dtype)
 
 
 def draws_for(shapes):
@@ -182,17 +192,21 @@ def one_iteration(net, ds, datas, fids, SP, timers=None):
         return p1, check
     torch.rand, torch.randn_like = draws.rand, draws.randn_like
     ref.utils.OptimizeSurfacePs = rec_refiner
+    real_float = torch.Tensor.float
+    if torch.get_default_dtype() == torch.float64:          # the reference writes `.float()` for "index -> floating point" (network.py:536, ...):
+        torch.Tensor.float = lambda self, *a, **k: self.to(torch.float64)      # in the double evaluation that must mean double
     try:
         loss = net(datas, SP, RATIO, fids)
+        info = dict(net.info)
+        loss.backward()
+        g_tmpps = net.TmpPs.grad.clone()
+        net.propagateTmpPsGrad(fids, RATIO)
     finally:
         torch.rand, torch.randn_like = real_rand, real_randn_like
         ref.utils.OptimizeSurfacePs = real_refiner
+        torch.Tensor.float = real_float
     kinds = [k for k, _ in draws.calls]
     assert kinds in (['rand', 'rand', 'randn_like', 'rand', 'rand', 'randn_like'], ['rand', 'randn_like', 'rand', 'rand', 'randn_like']), draws.calls
-    info = dict(net.info)
-    loss.backward()
-    g_tmpps = net.TmpPs.grad.clone()
-    net.propagateTmpPsGrad(fids, RATIO)
     return loss, info, draws, refined, g_tmpps
 
 
@@ -210,12 +224,12 @@ class TimedRaster:
         return out
 
 
-def run(stage, do_time=False, small=False):
+def run(stage, do_time=False, small=False, dtype=torch.float64, write=True):
     torch.set_num_threads(os.cpu_count())
     cfg = STAGES[stage]
     t0 = time.perf_counter()
     kw = dict(H=48, W=48, lbs_shape=(7, 11, 9), n_cube=10) if small else {}
-    net, ds, datas, fids, q, V0, faces = build(stage, **kw)
+    net, ds, datas, fids, q, V0, faces = build(stage, dtype=dtype, **kw)
     print(f"[{stage}] scene built in {time.perf_counter() - t0:.1f} s: V = {V0.shape[0]}, F = {faces.shape[0]}", flush=True)
     timers = {}
     net.maskRender, net.pcRender = TimedRaster(net.maskRender, timers, 'raster_mesh'), TimedRaster(net.pcRender, timers, 'raster_points')
@@ -226,7 +240,12 @@ def run(stage, do_time=False, small=False):
     print({k: v for k, v in info.items() if k != 'pc_loss'}, info['pc_loss'], flush=True)
     assert info['rayInfo'][1] > 0.2 * info['rayInfo'][0], info['rayInfo']
     sp, tp, rp = dict(net.sdf.named_parameters()), dict(net.deformer.defs[0].named_parameters()), dict(net.netRender.named_parameters())
-    arrs = dict(stage=np.array(stage), n_cube=np.array(cfg["n_cube"] if not small else 10), q=q.view(-1), fids=fids, HW=np.array(datas['img'].shape[1:3]), SP=np.array(cfg["SP"]), radius=np.array(cfg["radius"]),
+    # f at the MOVED template vertices (the argument of the L1 term 60 * mean |f(TmpVs)|, network.py:690-694; its gradient is sign(f) per
+    # vertex): stored so that a test can tell a real mismatch from sign flips of |f| ~ 1e-6 entries.  float16 of 1024 f (|f| < 4e-3).
+    with torch.no_grad():
+        f_moved = torch.cat([net.sdf(part, RATIO)[:, 0] for part in torch.split(net.TmpVs.detach(), 20000)])
+    arrs = dict(f_moved_x1024=(f_moved * 1024.).to(torch.float16), pc_weight=np.array(net.conf.get_float('pc_weight.weight')),
+                dtype_bits=np.array(64 if dtype == torch.float64 else 32), n_cube=np.array(cfg["n_cube"] if not small else 10), q=q.view(-1), fids=fids, HW=np.array(datas['img'].shape[1:3]), SP=np.array(cfg["SP"]), radius=np.array(cfg["radius"]),
                 ang_thr=np.array(net.angThred), frame_num=np.array(ds.frame_num), lbs_shape=np.array(net.deformer.defs[1].ws.shape[2:]),
                 draw_shapes=np.array([list(s) + [0] * (2 - len(s)) for _, s in draws.calls]), loss=loss.detach(),
                 ray_info=np.array(info['rayInfo']), inv_info=np.array(net.info['invInfo']),
@@ -241,8 +260,9 @@ def run(stage, do_time=False, small=False):
             arrs[f"d_{tag}.{name}"] = param_digest(p.grad, 100 * k)
             arrs[f"s_{tag}.{name}"] = slice_of(p.grad)
     conv = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()}
+    conv = {k: (v.astype(np.float32) if (v.dtype == np.float64 and v.size > 8) else v) for k, v in conv.items()}     # values of the double run, stored in single
     name = f"iteration_full_{stage}" + ("_small" if small else "")
-    if not small:
+    if not small and write:
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **conv)
         print("wrote", name, os.path.getsize(os.path.join(OUT, name + ".npz")), "bytes", flush=True)
     rec = None
@@ -270,13 +290,18 @@ if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if not a.startswith("--")]
     stages = ["coarse", "fine"] if (not which or which[0] == "both") else [which[0]]
     small = "--small" in sys.argv
-    recs = [run(s, "--time" in sys.argv, small) for s in stages]
+    recs = []
+    for st in stages:
+        if "--no-golden" not in sys.argv:
+            run(st, False, small, torch.float64)                          # the fixture: the reference's algorithm evaluated in double
+        if "--time" in sys.argv:
+            recs.append(run(st, True, small, torch.float32, write=False))    # the baseline: the reference as it runs, float32
     if "--time" in sys.argv and not small:
         out = {"kind": "reference",
                "what": "the reference's own OptimNetwork.forward + loss.backward() + propagateTmpPsGrad (model/network.py:451-814) on the reference's own modules "
                        "(oracle/gen_fullsize_golden.py harness), full configs[1] size, CPU; the pytorch3d rasterisers (third-party, restated in numpy) are "
                        "excluded from seconds_per_iteration; remesh and the Adam step are not part of the call",
-               "where": "build container", "cores": os.cpu_count(), "torch_threads": torch.get_num_threads(), "protocol": "warm-up 1 (the golden run) + median of 3",
+               "where": "build container", "cores": os.cpu_count(), "torch_threads": torch.get_num_threads(), "dtype": "f32", "protocol": "warm-up 1 + median of 3",
                "stages": [r for r in recs if r]}
         with open(os.path.join(ROOT, "profiles", "r03_cpu_reference.json"), "w") as fh:
             json.dump(out, fh, indent=1)

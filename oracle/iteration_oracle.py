@@ -59,6 +59,7 @@ def pc_loss(sc, TmpVs, tmp_opt, defTmpVs, dcond, poses, trans, masks, gtMs, rati
     pred = orc.sdf_forward(sc.sdf, TmpVs, ratio)[0].view(-1)
     sdf_loss = pred.abs().mean()
     info['pc_loss_sdf'] = sdf_loss.detach()
+    info['tmpl_pred'] = pred.detach()           # f at the moved template vertices: the tests look at its signs (gradient of the L1 term)
     return sdf_loss * (conf.get_float('pc_weight.weight') if 'pc_weight' in conf else 60.)
 
 

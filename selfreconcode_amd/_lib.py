@@ -150,8 +150,9 @@ SIGNATURES = {
     "sr_lbs_chain_fwd": [_vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp],
     "sr_lbs_chain_bwd": [_vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sr_lbs_fwd": [_vp, _vp],
-    "sr_lbs_bwd": [_vp, _vp, _vp, _vp, _vp, _vp],
-    "sr_lbs_jac_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sr_lbs_bwd_workspace_floats": [_i64, ctypes.c_int32],
+    "sr_lbs_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sr_lbs_jac_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sr_newton_update": [_vp, _vp],
     "sr_newton_prepare": [_vp, _vp],
     "sr_newton_apply": [_vp, _vp],
@@ -195,7 +196,7 @@ SIGNATURES = {
     "sr_pe_embed_bwd": [_vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _i64, _vp, _vp],
     "sr_pe_embed": [_vp, _i64, ctypes.c_int32, _vp, _vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _i64, _vp],
 }
-_RESTYPE = {"sr_mlp_gemm_tn_workspace_floats": _i64, "sr_mc_workspace_bytes": _i64, "sr_points_silhouette_workspace_bytes": _i64}
+_RESTYPE = {"sr_lbs_bwd_workspace_floats": _i64, "sr_mlp_gemm_tn_workspace_floats": _i64, "sr_mc_workspace_bytes": _i64, "sr_points_silhouette_workspace_bytes": _i64}
 
 _fn = {}
 for _name, _args in SIGNATURES.items():

@@ -59,32 +59,62 @@ __device__ __forceinline__ float wave_sum(float v) {
          __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
 }
 
+// Deterministic per-frame accumulation (both backward kernels).  A lane's contribution belongs to the frame of its point; the lanes of
+// a wave are reduced frame by frame (one pass per distinct frame among the 64 lanes: one pass when the points come sorted by
+// frame, as every caller of the training step passes them; at most `nframes` passes for any order) with the DPP butterfly, and lane
+// 0 adds the wave's total into the WAVE'S OWN accumulator row in LDS -- plain read-modify-writes in program order, no atomics.
+// The four rows of a workgroup are folded in a fixed order into a per-workgroup partial in global memory, and a second launch sums
+// the partials of all workgroups in double precision, again in a fixed order.  The result is bit-reproducible run to run and
+// independent of the schedule; its rounding error is that of a 64-lane butterfly plus one double-precision sum.
+struct FramePass {
+  unsigned long long todo;
+  __device__ __forceinline__ FramePass() : todo(~0ull) {}
+  // -> true while a frame is pending; sets f (wave-uniform) and mine (this lane belongs to it)
+  __device__ __forceinline__ bool next(int frame, int& f, bool& mine) {
+    if (!todo) return false;
+    const int src = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)todo) - 1);
+    f = __builtin_amdgcn_readlane(frame, src);
+    mine = frame == f;
+    todo &= ~__ballot(mine);
+    return true;
+  }
+};
+
+__global__ __launch_bounds__(256) void lbs_reduce_partials(const float* __restrict__ partials, int nblocks, int nframes,
+                                                            float* __restrict__ Abar, float* __restrict__ tbar) {
+  const int per = NJ * 12 + 3, n = nframes * per;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)partials[(int64_t)b * n + i];
+    const int f = i / per, e = i % per;
+    if (e < NJ * 12) { if (Abar) Abar[(int64_t)f * NJ * 12 + e] = (float)s; }
+    else if (tbar) tbar[f * 3 + (e - NJ * 12)] = (float)s;
+  }
+}
+
 // Backward of y = LBS(p) for a cotangent ybar [P,3]:  pbar = J^T ybar (analytic Jacobian incl. the sampler term),
-// Abar[frame][j] += w_j ybar (x) [p;1],  transbar[frame] += ybar.  Per-workgroup partial sums of Abar / transbar
-// live in LDS and are flushed with one atomicAdd per entry (Guideline 12: reduce first, then one atomic per block).
+// Abar[frame][j] = sum w_j ybar (x) [p;1],  transbar[frame] = sum ybar  (deterministic, see FramePass above).
 __global__ __launch_bounds__(256) void lbs_bwd_kernel(sr_lbs_args g, const float* __restrict__ ybar, float* __restrict__ pbar,
-                                                       float* __restrict__ Abar, float* __restrict__ tbar) {
-  extern __shared__ float sacc[];                 // nframes * (24*12 + 3)
+                                                       bool want_A, bool want_t, float* __restrict__ partials) {
+  extern __shared__ float sacc[];                 // 4 waves x nframes x (24*12 + 3)
   const int per = NJ * 12 + 3;
-  for (int i = threadIdx.x; i < g.nframes * per; i += blockDim.x) sacc[i] = 0.f;
+  for (int i = threadIdx.x; i < 4 * g.nframes * per; i += blockDim.x) sacc[i] = 0.f;
   __syncthreads();
+  float* wacc = sacc + (threadIdx.x >> 6) * g.nframes * per;      // this wave's accumulator rows
+  const bool lane0 = (threadIdx.x & 63) == 0;
   const int64_t sH = (int64_t)g.W * NJ, sD = (int64_t)g.H * g.W * NJ;
   for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < g.P; base += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t idx = base + threadIdx.x;
-    if (idx < g.P) {
+    const bool valid = base + threadIdx.x < g.P;                  // lanes past the end run along on the last point with a zero cotangent:
+    const int64_t idx = valid ? base + threadIdx.x : g.P - 1;     // the wave-wide reductions below need all 64 lanes
+    {
       const float px = g.p[idx * 3], py = g.p[idx * 3 + 1], pz = g.p[idx * 3 + 2];
-      const float bx = ybar[idx * 3], by = ybar[idx * 3 + 1], bz = ybar[idx * 3 + 2];
+      const float bx = valid ? ybar[idx * 3] : 0.f, by = valid ? ybar[idx * 3 + 1] : 0.f, bz = valid ? ybar[idx * 3 + 2] : 0.f;
       const Axis ax = make_axis(px, g.bmin[0], g.bmax[0], g.W);
       const Axis ay = make_axis(py, g.bmin[1], g.bmax[1], g.H);
       const Axis az = make_axis(pz, g.bmin[2], g.bmax[2], g.D);
       const int frame = g.batch_inds ? (int)g.batch_inds[idx] : (int)(idx / g.points_per_frame);
       const float* Af = g.A + (int64_t)frame * NJ * 12;
-      float* acc = sacc + frame * per;
-      float w[NJ], s[NJ];
-      // a full wave whose 64 points share one frame sums its contributions in registers (DPP) and issues ONE LDS atomic
-      // per word; ragged / mixed-frame waves keep the per-lane LDS atomics
-      const bool full_wave = base + (int64_t)(threadIdx.x | 63) < g.P;
-      const bool uniform = full_wave && __all(frame == __builtin_amdgcn_readfirstlane(frame));                           // weights and s_j = ybar . (A_j [p;1])
+      float w[NJ], s[NJ];                           // weights and s_j = ybar . (A_j [p;1])
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const float* a = Af + j * 12;
@@ -120,32 +150,29 @@ __global__ __launch_bounds__(256) void lbs_bwd_kernel(sr_lbs_args g, const float
         for (int r = 0; r < 3; ++r)
 #pragma unroll
           for (int c = 0; c < 3; ++c) T[r * 3 + c] += w[j] * a[r * 4 + c];
-        if (Abar) {
+        if (want_A) {
           const float wj = w[j];
-          float* o = acc + j * 12;
           const float c12[12] = {wj * bx * px, wj * bx * py, wj * bx * pz, wj * bx, wj * by * px, wj * by * py, wj * by * pz, wj * by,
                                  wj * bz * px, wj * bz * py, wj * bz * pz, wj * bz};
-          if (uniform) {          // all 64 lanes hit the same 12 words: butterfly-sum in registers, ONE LDS atomic per word per wave
+          FramePass fp; int f; bool mine;
+          while (fp.next(frame, f, mine)) {
+            float* o = wacc + f * per + j * 12;
 #pragma unroll
             for (int e = 0; e < 12; ++e) {
-              const float v = wave_sum(c12[e]);
-              if ((threadIdx.x & 63) == 0) atomicAdd(o + e, v);
+              const float v = wave_sum(mine ? c12[e] : 0.f);
+              if (lane0) o[e] += v;
             }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 12; ++e) atomicAdd(o + e, c12[e]);
           }
         }
       }
-      if (tbar) {
-        if (uniform) {
-          const float sx = wave_sum(bx), sy = wave_sum(by), sz = wave_sum(bz);
-          if ((threadIdx.x & 63) == 0) { atomicAdd(acc + NJ * 12, sx); atomicAdd(acc + NJ * 12 + 1, sy); atomicAdd(acc + NJ * 12 + 2, sz); }
-        } else {
-          atomicAdd(acc + NJ * 12, bx); atomicAdd(acc + NJ * 12 + 1, by); atomicAdd(acc + NJ * 12 + 2, bz);
+      if (want_t) {
+        FramePass fp; int f; bool mine;
+        while (fp.next(frame, f, mine)) {
+          const float sx = wave_sum(mine ? bx : 0.f), sy = wave_sum(mine ? by : 0.f), sz = wave_sum(mine ? bz : 0.f);
+          if (lane0) { float* o = wacc + f * per + NJ * 12; o[0] += sx; o[1] += sy; o[2] += sz; }
         }
       }
-      if (pbar) {
+      if (pbar && valid) {
         pbar[idx * 3 + 0] = T[0] * bx + T[3] * by + T[6] * bz + gu * ax.du;
         pbar[idx * 3 + 1] = T[1] * bx + T[4] * by + T[7] * bz + gv * ay.du;
         pbar[idx * 3 + 2] = T[2] * bx + T[5] * by + T[8] * bz + gw * az.du;
@@ -153,13 +180,9 @@ __global__ __launch_bounds__(256) void lbs_bwd_kernel(sr_lbs_args g, const float
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < g.nframes * per; i += blockDim.x) {
-    const int f = i / per, e = i % per;
-    const float v = sacc[i];
-    if (v == 0.f) continue;
-    if (e < NJ * 12) { if (Abar) atomicAdd(Abar + (int64_t)f * NJ * 12 + e, v); }
-    else if (tbar) atomicAdd(tbar + f * 3 + (e - NJ * 12), v);
-  }
+  const int n = g.nframes * per;
+  for (int i = threadIdx.x; i < n; i += blockDim.x)                 // the four wave rows, in a fixed order
+    partials[(int64_t)blockIdx.x * n + i] = ((sacc[i] + sacc[n + i]) + sacc[2 * n + i]) + sacc[3 * n + i];
 }
 
 // Backward of (y, J) = sr_lbs_fwd with its analytic Jacobian, for cotangents ybar [P,3] (nullable) and Jbar [P,3,3]:
@@ -171,28 +194,28 @@ __global__ __launch_bounds__(256) void lbs_bwd_kernel(sr_lbs_args g, const float
 // Two sweeps over the 8 corners (the second one hits the cache): the first rebuilds w_j and grad w_j, the joint loop between
 // them emits Abar and replaces (w, grad w) by (e, gam) in the same registers, the second contracts the corners with (e, gam).
 __global__ __launch_bounds__(256) void lbs_jac_bwd_kernel(sr_lbs_args g, const float* __restrict__ ybar, const float* __restrict__ Jbar,
-                                                           float* __restrict__ pbar, float* __restrict__ Abar, float* __restrict__ tbar) {
-  extern __shared__ float sacc[];                 // nframes * (24*12 + 3)
+                                                           float* __restrict__ pbar, bool want_A, bool want_t, float* __restrict__ partials) {
+  extern __shared__ float sacc[];                 // 4 waves x nframes x (24*12 + 3)
   const int per = NJ * 12 + 3;
-  for (int i = threadIdx.x; i < g.nframes * per; i += blockDim.x) sacc[i] = 0.f;
+  for (int i = threadIdx.x; i < 4 * g.nframes * per; i += blockDim.x) sacc[i] = 0.f;
   __syncthreads();
+  float* wacc = sacc + (threadIdx.x >> 6) * g.nframes * per;
+  const bool lane0 = (threadIdx.x & 63) == 0;
   const int64_t sH = (int64_t)g.W * NJ, sD = (int64_t)g.H * g.W * NJ;
   for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < g.P; base += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t idx = base + threadIdx.x;
-    if (idx < g.P) {
+    const bool valid = base + threadIdx.x < g.P;                  // (see lbs_bwd_kernel)
+    const int64_t idx = valid ? base + threadIdx.x : g.P - 1;
+    {
       const float q[3] = {g.p[idx * 3], g.p[idx * 3 + 1], g.p[idx * 3 + 2]};
       float yb[3] = {0.f, 0.f, 0.f}, Jb[9];
-      if (ybar) { yb[0] = ybar[idx * 3]; yb[1] = ybar[idx * 3 + 1]; yb[2] = ybar[idx * 3 + 2]; }
+      if (ybar && valid) { yb[0] = ybar[idx * 3]; yb[1] = ybar[idx * 3 + 1]; yb[2] = ybar[idx * 3 + 2]; }
 #pragma unroll
-      for (int e = 0; e < 9; ++e) Jb[e] = Jbar[idx * 9 + e];
+      for (int e = 0; e < 9; ++e) Jb[e] = valid ? Jbar[idx * 9 + e] : 0.f;
       const Axis ax = make_axis(q[0], g.bmin[0], g.bmax[0], g.W);
       const Axis ay = make_axis(q[1], g.bmin[1], g.bmax[1], g.H);
       const Axis az = make_axis(q[2], g.bmin[2], g.bmax[2], g.D);
       const int frame = g.batch_inds ? (int)g.batch_inds[idx] : (int)(idx / g.points_per_frame);
       const float* Af = g.A + (int64_t)frame * NJ * 12;
-      float* acc = sacc + frame * per;
-      const bool full_wave = base + (int64_t)(threadIdx.x | 63) < g.P;
-      const bool uniform = full_wave && __all(frame == __builtin_amdgcn_readfirstlane(frame));
       // The joints are processed in two halves of 12 (every sum over j is additive): half the coefficient registers, and each half
       // reads only its own 48 bytes of a corner's 96-byte run.
       float T[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, m[3] = {0.f, 0.f, 0.f};
@@ -236,8 +259,7 @@ __global__ __launch_bounds__(256) void lbs_jac_bwd_kernel(sr_lbs_args g, const f
 #pragma unroll
             for (int c = 0; c < 3; ++c) { T[r * 3 + c] += wj * a[r * 4 + c]; m[c] += a[r * 4 + c] * jg; }
           }
-          if (Abar) {
-            float* o = acc + (j0 + j) * 12;
+          if (want_A) {
             float c12[12];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -245,15 +267,14 @@ __global__ __launch_bounds__(256) void lbs_jac_bwd_kernel(sr_lbs_args g, const f
               for (int c = 0; c < 3; ++c) c12[r * 4 + c] = u[r] * q[c] + wj * Jb[r * 3 + c];
               c12[r * 4 + 3] = u[r];
             }
-            if (uniform) {
+            FramePass fp; int f; bool mine;
+            while (fp.next(frame, f, mine)) {
+              float* o = wacc + f * per + (j0 + j) * 12;
 #pragma unroll
               for (int e = 0; e < 12; ++e) {
-                const float v = wave_sum(c12[e]);
-                if ((threadIdx.x & 63) == 0) atomicAdd(o + e, v);
+                const float v = wave_sum(mine ? c12[e] : 0.f);
+                if (lane0) o[e] += v;
               }
-            } else {
-#pragma unroll
-              for (int e = 0; e < 12; ++e) atomicAdd(o + e, c12[e]);
             }
           }
           float ej = yb[0] * v3[0] + yb[1] * v3[1] + yb[2] * v3[2];
@@ -289,15 +310,14 @@ __global__ __launch_bounds__(256) void lbs_jac_bwd_kernel(sr_lbs_args g, const f
           }
         }
       }
-      if (tbar && ybar) {
-        if (uniform) {
-          const float sx = wave_sum(yb[0]), sy = wave_sum(yb[1]), sz = wave_sum(yb[2]);
-          if ((threadIdx.x & 63) == 0) { atomicAdd(acc + NJ * 12, sx); atomicAdd(acc + NJ * 12 + 1, sy); atomicAdd(acc + NJ * 12 + 2, sz); }
-        } else {
-          atomicAdd(acc + NJ * 12, yb[0]); atomicAdd(acc + NJ * 12 + 1, yb[1]); atomicAdd(acc + NJ * 12 + 2, yb[2]);
+      if (want_t && ybar) {
+        FramePass fp; int f; bool mine;
+        while (fp.next(frame, f, mine)) {
+          const float sx = wave_sum(mine ? yb[0] : 0.f), sy = wave_sum(mine ? yb[1] : 0.f), sz = wave_sum(mine ? yb[2] : 0.f);
+          if (lane0) { float* o = wacc + f * per + NJ * 12; o[0] += sx; o[1] += sy; o[2] += sz; }
         }
       }
-      if (pbar) {
+      if (pbar && valid) {
         pbar[idx * 3 + 0] = T[0] * yb[0] + T[3] * yb[1] + T[6] * yb[2] + m[0] + ax.du * (gu + ay.du * hxy_y + az.du * hxz_z);
         pbar[idx * 3 + 1] = T[1] * yb[0] + T[4] * yb[1] + T[7] * yb[2] + m[1] + ay.du * (gv + ax.du * hxy_x + az.du * hyz_z);
         pbar[idx * 3 + 2] = T[2] * yb[0] + T[5] * yb[1] + T[8] * yb[2] + m[2] + az.du * (gw_ + ax.du * hxz_x + ay.du * hyz_y);
@@ -305,26 +325,47 @@ __global__ __launch_bounds__(256) void lbs_jac_bwd_kernel(sr_lbs_args g, const f
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < g.nframes * per; i += blockDim.x) {
-    const int f = i / per, e = i % per;
-    const float v = sacc[i];
-    if (v == 0.f) continue;
-    if (e < NJ * 12) { if (Abar) atomicAdd(Abar + (int64_t)f * NJ * 12 + e, v); }
-    else if (tbar) atomicAdd(tbar + f * 3 + (e - NJ * 12), v);
-  }
+  const int n = g.nframes * per;
+  for (int i = threadIdx.x; i < n; i += blockDim.x)                 // the four wave rows, in a fixed order
+    partials[(int64_t)blockIdx.x * n + i] = ((sacc[i] + sacc[n + i]) + sacc[2 * n + i]) + sacc[3 * n + i];
 }
 }  // namespace
 
-extern "C" int sr_lbs_jac_bwd(const sr_lbs_args* a, const float* ybar, const float* Jbar, float* pbar, float* Abar, float* transbar, void* stream) {
-  if (!a || a->P < 0 || a->nframes <= 0 || a->nframes > 32 || a->D <= 0 || a->H <= 0 || a->W <= 0) return SR_EINVAL;
-  if (a->P == 0) return SR_OK;
-  if (!a->p || !a->A || !a->vol || !Jbar || a->tp || ((uintptr_t)a->vol & 15)) return SR_EINVAL;
-  if (!a->batch_inds && a->points_per_frame <= 0) return SR_EINVAL;
-  int grid = sr_stream_grid(a->P, 256);
-  if (grid > 512) grid = 512;
-  const size_t lds = (size_t)a->nframes * (NJ * 12 + 3) * sizeof(float);
-  hipLaunchKernelGGL(lbs_jac_bwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, *a, ybar, Jbar, pbar, Abar, transbar);
+static int lbs_bwd_grid(int64_t P) {
+  int grid = sr_stream_grid(P, 256);
+  return grid > 512 ? 512 : grid;                  // fewer, fatter workgroups: fewer partial rows to fold
+}
+
+// floats of the `partials` workspace of sr_lbs_bwd / sr_lbs_jac_bwd (one row of nframes x 291 sums per workgroup)
+extern "C" int64_t sr_lbs_bwd_workspace_floats(int64_t P, int32_t nframes) {
+  if (P < 0 || nframes <= 0) return SR_EINVAL;
+  return (int64_t)(P > 0 ? lbs_bwd_grid(P) : 0) * nframes * (NJ * 12 + 3);
+}
+
+template <class K, class... Args>
+static int lbs_bwd_launch(K kernel, const sr_lbs_args* a, float* Abar, float* transbar, float* partials, void* stream, Args... args) {
+  const int grid = lbs_bwd_grid(a->P);
+  const size_t lds = (size_t)4 * a->nframes * (NJ * 12 + 3) * sizeof(float);
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SR_ELAUNCH;
+  const bool want = Abar || transbar;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, *a, args..., Abar != nullptr, transbar != nullptr, partials);
+  if (want)
+    hipLaunchKernelGGL(lbs_reduce_partials, dim3(sr_cdiv(a->nframes * (NJ * 12 + 3), 256)), dim3(256), 0, (hipStream_t)stream, partials, grid, a->nframes,
+                       Abar, transbar);
   return sr_launch_status();
+}
+
+extern "C" int sr_lbs_jac_bwd(const sr_lbs_args* a, const float* ybar, const float* Jbar, float* pbar, float* Abar, float* transbar, float* partials,
+                              void* stream) {
+  if (!a || a->P < 0 || a->nframes <= 0 || a->nframes > 32 || a->D <= 0 || a->H <= 0 || a->W <= 0) return SR_EINVAL;
+  if (a->P == 0) {                                   // no points: the sums are zero
+    if (Abar && hipMemsetAsync(Abar, 0, sizeof(float) * a->nframes * NJ * 12, (hipStream_t)stream) != hipSuccess) return SR_ELAUNCH;
+    if (transbar && hipMemsetAsync(transbar, 0, sizeof(float) * a->nframes * 3, (hipStream_t)stream) != hipSuccess) return SR_ELAUNCH;
+    return SR_OK;
+  }
+  if (!a->p || !a->A || !a->vol || !Jbar || a->tp || ((uintptr_t)a->vol & 15) || !partials) return SR_EINVAL;
+  if (!a->batch_inds && a->points_per_frame <= 0) return SR_EINVAL;
+  return lbs_bwd_launch(lbs_jac_bwd_kernel, a, Abar, transbar, partials, stream, ybar, Jbar, pbar);
 }
 
 extern "C" int sr_lbs_fwd(const sr_lbs_args* a, void* stream) {
@@ -339,18 +380,18 @@ extern "C" int sr_lbs_fwd(const sr_lbs_args* a, void* stream) {
   return sr_launch_status();
 }
 
-// Reverse of sr_lbs_fwd (weights looked up at p itself).  Abar [nframes,24,12] and transbar [nframes,3] must be
-// zero-filled by the caller (they are accumulated); any of pbar / Abar / transbar may be NULL.
-extern "C" int sr_lbs_bwd(const sr_lbs_args* a, const float* ybar, float* pbar, float* Abar, float* transbar, void* stream) {
+// Reverse of sr_lbs_fwd (weights looked up at p itself).  Abar [nframes,24,12] and transbar [nframes,3] are WRITTEN (no zero fill
+// needed); any of pbar / Abar / transbar may be NULL.  `partials`: sr_lbs_bwd_workspace_floats(P, nframes) floats of scratch.
+extern "C" int sr_lbs_bwd(const sr_lbs_args* a, const float* ybar, float* pbar, float* Abar, float* transbar, float* partials, void* stream) {
   if (!a || a->P < 0 || a->nframes <= 0 || a->nframes > 32 || a->D <= 0 || a->H <= 0 || a->W <= 0) return SR_EINVAL;
-  if (a->P == 0) return SR_OK;
-  if (!a->p || !a->A || !a->vol || !ybar || a->tp || ((uintptr_t)a->vol & 15)) return SR_EINVAL;
+  if (a->P == 0) {
+    if (Abar && hipMemsetAsync(Abar, 0, sizeof(float) * a->nframes * NJ * 12, (hipStream_t)stream) != hipSuccess) return SR_ELAUNCH;
+    if (transbar && hipMemsetAsync(transbar, 0, sizeof(float) * a->nframes * 3, (hipStream_t)stream) != hipSuccess) return SR_ELAUNCH;
+    return SR_OK;
+  }
+  if (!a->p || !a->A || !a->vol || !ybar || a->tp || ((uintptr_t)a->vol & 15) || !partials) return SR_EINVAL;
   if (!a->batch_inds && a->points_per_frame <= 0) return SR_EINVAL;
-  int grid = sr_stream_grid(a->P, 256);
-  if (grid > 512) grid = 512;                      // fewer, fatter workgroups: fewer global atomics for Abar
-  const size_t lds = (size_t)a->nframes * (NJ * 12 + 3) * sizeof(float);
-  hipLaunchKernelGGL(lbs_bwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, *a, ybar, pbar, Abar, transbar);
-  return sr_launch_status();
+  return lbs_bwd_launch(lbs_bwd_kernel, a, Abar, transbar, partials, stream, ybar, pbar);
 }
 
 // ------------------------------------------------------------------------------------------------

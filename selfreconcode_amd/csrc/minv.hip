@@ -3,6 +3,9 @@
 // backward -(C^T G C^T)).  HBM-bound (73 B/matrix fwd, 108 B/matrix bwd): a workgroup moves
 // 256 matrices (2304 scalars) through LDS so that every global access is a coalesced dword
 // stream; the stride-9 LDS reads are conflict-free (9 is odd).
+// The per-matrix arithmetic keeps the reference's operation order with every operation rounded on its own (no mul+add
+// contraction): results are BIT-EQUAL to the reference's kernels compiled for the host (oracle/_ref/libminv_ref_nofma.so,
+// tests/test_minv_reference_pin.py), in float32 and float64, including which matrices are flagged singular.
 #include "sr_common.h"
 
 namespace {
@@ -20,6 +23,7 @@ __global__ __launch_bounds__(kMat) void minv_fwd_kernel(const T* __restrict__ ms
     __syncthreads();
     const int t = threadIdx.x;
     if (t < cnt) {
+#pragma clang fp contract(off)
       T* m = tile + t * 9;
       const T m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5], m20 = m[6], m21 = m[7], m22 = m[8];
       const T c00 = m11 * m22 - m12 * m21;
@@ -65,19 +69,21 @@ __global__ __launch_bounds__(kMat) void minv_bwd_kernel(const T* __restrict__ gr
     __syncthreads();
     const int t = threadIdx.x;
     if (t < cnt) {
-      T g[9], c[9], tmp[9];
+#pragma clang fp contract(off)
+      T g[9], c[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) { g[i] = gt[t * 9 + i]; c[i] = ct[t * 9 + i]; }
-      // tmp = C^T G ; out = -(tmp C^T):  out[a][b] = -sum_{i,j} C[i][a] G[i][j] C[b][j]
+      // out[a][b] = -sum_{i,j} (G[i][j] C[i][a]) C[b][j], the nine terms added left to right with i outer, j inner: the
+      // expression order of Matrix3x3InvKernels.cu:91-101 (HBM-bound kernel: the 162 multiplies cost nothing)
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) tmp[a * 3 + j] = c[0 * 3 + a] * g[0 * 3 + j] + c[1 * 3 + a] * g[1 * 3 + j] + c[2 * 3 + a] * g[2 * 3 + j];
+        for (int b = 0; b < 3; ++b) {
+          T acc = (g[0] * c[a]) * c[b * 3];
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-          gt[t * 9 + a * 3 + b] = -(tmp[a * 3 + 0] * c[b * 3 + 0] + tmp[a * 3 + 1] * c[b * 3 + 1] + tmp[a * 3 + 2] * c[b * 3 + 2]);
+          for (int ij = 1; ij < 9; ++ij) acc = acc + (g[ij] * c[(ij / 3) * 3 + a]) * c[b * 3 + ij % 3];
+          gt[t * 9 + a * 3 + b] = -acc;
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < cnt * 9; i += kMat) outs[base * 9 + i] = gt[i];
@@ -102,7 +108,7 @@ int minv_bwd(const T* grads, const T* invs, T* outs, int64_t n, void* stream) {
 }  // namespace
 
 extern "C" {
-int sr_abi_version(void) { return 1; }
+int sr_abi_version(void) { return 2; }
 const char* sr_build_arch(void) { return "gfx950"; }
 // digest of the sources this library was built from (selfreconcode_amd/build.py passes it; the marker string is what build.py
 // looks for inside the .so to decide whether the library matches the tree -- no side file needed)

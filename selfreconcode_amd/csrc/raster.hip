@@ -7,7 +7,10 @@
 //        mask[pixel] = sum_k a_k prod_{j<k} (1 - a_j)   over the K points NEAREST IN Z that cover the pixel,
 //        a = 1 - dist2 / r^2,  dist2 < r^2 (NDC units),  points with z < 0 skipped.
 //    With unit features the composite is 1 - prod_k (1 - a_k): commutative, so pixels covered by <= K points are
-//    accumulated as sum_k log(1 - a_k) with atomics, in one pass over the points and with no per-pixel lists.  Only the
+//    accumulated as sum_k log(1 - a_k) with atomics, in one pass over the points and with no per-pixel lists.  The sum is kept
+//    in FIXED POINT and shares one 64-bit word with the pair count (one integer atomic per pair instead of a float and an
+//    integer one): integer addition is associative, so the result does not depend on the order in which the atomics land --
+//    the image, and everything the training step derives from it, is bit-reproducible run to run.  Only the
 //    pixels that more than K points cover (silhouette rims at grazing angles; none to a few hundred per image) go
 //    through the selection: their (z, point) keys are gathered into buckets, a wave per pixel finds the K-th smallest
 //    key by a 64-step binary search on the key bits, and the pixel is re-composited from the keys up to that threshold.
@@ -46,9 +49,23 @@ __device__ __forceinline__ bool point_ok(float px, float py, float z) {
   return z >= 0.f && fabsf(px) < 4.f && fabsf(py) < 4.f;       // behind the camera / NaN / absurdly far off screen
 }
 
-// Pass 1: every (point, covered pixel) pair: count and sum of log(1 - a).
+// Packed accumulator of a pixel: low kCountBits = number of covering points, the bits above = sum of round(log(1 - a) * 2^frac)
+// (two's complement).  frac is chosen from K so that the sum field holds K terms of log(1 - a) >= log(1e-6) = -13.8 exactly; pixels
+// covered by more than K points may wrap it -- they are re-composited from their keys by ps_select.
+constexpr int kCountBits = 22;
+__host__ __device__ inline int ps_frac_bits(int K) {
+  int ib = 1;                                   // integer bits (incl. sign) for |sum| <= 14 K
+  while ((1ll << (ib - 1)) <= 14ll * K) ++ib;
+  const int f = 64 - kCountBits - ib;
+  return f > 36 ? 36 : f;
+}
+__device__ __forceinline__ long long ps_quantise(float d2, float r2, float scale) {
+  return __float2ll_rn(__logf(1.0f - fminf(1.0f - d2 / r2, kAlphaMax)) * scale);        // <= 0
+}
+
+// Pass 1: every (point, covered pixel) pair: ONE 64-bit integer atomic (count + fixed-point log(1 - a)).
 __global__ __launch_bounds__(256) void ps_accumulate(const float* __restrict__ xy, const float* __restrict__ z, int64_t npts, int64_t V,
-                                                      int H, int W, float radius, uint32_t* __restrict__ count, float* __restrict__ logT) {
+                                                      int H, int W, float radius, float scale, unsigned long long* __restrict__ acc) {
   const float r2 = radius * radius;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += (int64_t)gridDim.x * blockDim.x) {
     const float px = xy[i * 2], py = xy[i * 2 + 1];
@@ -62,8 +79,7 @@ __global__ __launch_bounds__(256) void ps_accumulate(const float* __restrict__ x
         const float d2 = dx * dx + dy * dy;
         if (!(d2 < r2)) continue;
         const int64_t o = (img * H + r) * W + c;
-        atomicAdd(count + o, 1u);
-        atomicAdd(logT + o, __logf(1.0f - fminf(1.0f - d2 / r2, kAlphaMax)));
+        atomicAdd(acc + o, (unsigned long long)(ps_quantise(d2, r2, scale) * (1ll << kCountBits) + 1ll));
       }
     }
   }
@@ -71,15 +87,20 @@ __global__ __launch_bounds__(256) void ps_accumulate(const float* __restrict__ x
 
 // Pass 2: per pixel: finish the common case, queue the pixels that more than K points cover.
 // over[0] = number of queued pixels, over[1] = number of keys their buckets hold.
-__global__ __launch_bounds__(256) void ps_resolve(int64_t npix, int K, const uint32_t* __restrict__ count, const float* __restrict__ logT,
+__global__ __launch_bounds__(256) void ps_resolve(int64_t npix, int K, float inv_scale, const unsigned long long* __restrict__ acc,
+                                                   uint32_t* __restrict__ count, float* __restrict__ logT,
                                                    float* __restrict__ mask, unsigned long long* __restrict__ thresh,
                                                    int32_t* __restrict__ slot_of, unsigned long long* __restrict__ over,
                                                    int64_t* __restrict__ over_pix, int64_t* __restrict__ over_off) {
   for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < npix; o += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t n = count[o];
+    const unsigned long long packed = acc[o];
+    const uint32_t n = (uint32_t)(packed & ((1ull << kCountBits) - 1));          // (2^22 or more points per image would let it wrap: refused by the launcher)
+    const float lt = (float)((long long)packed >> kCountBits) * inv_scale;       // arithmetic shift: the signed fixed-point sum
+    count[o] = n;
+    logT[o] = lt;
     thresh[o] = ~0ull;
     slot_of[o] = -1;
-    mask[o] = 1.0f - __expf(logT[o]);
+    mask[o] = 1.0f - __expf(lt);
     if (n > (uint32_t)K) {
       const unsigned long long slot = atomicAdd(over, 1ull);
       over_pix[slot] = o;
@@ -126,8 +147,14 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
 }
 
 // Pass 4: one wave per queued pixel: K-th smallest key (binary search on the 64 key bits), then the composite of the
-// keys up to it, summed in a fixed lane order (deterministic).
-__global__ __launch_bounds__(256) void ps_select(const float* __restrict__ xy, int H, int W, float radius, int K, const uint32_t* __restrict__ count,
+// keys up to it (integer sums: deterministic whatever order the bucket was filled in).
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void ps_select(const float* __restrict__ xy, int H, int W, float radius, int K, float scale, const uint32_t* __restrict__ count,
                                                   const unsigned long long* __restrict__ over, const int64_t* __restrict__ over_pix,
                                                   const int64_t* __restrict__ over_off, const unsigned long long* __restrict__ bucket,
                                                   float* __restrict__ mask, float* __restrict__ logT, unsigned long long* __restrict__ thresh) {
@@ -153,15 +180,16 @@ __global__ __launch_bounds__(256) void ps_select(const float* __restrict__ xy, i
     }
     const int c = (int)(o % W), r = (int)((o / W) % H);
     const float xf = pix_to_ndc(c, W), yf = pix_to_ndc(r, H);
-    float acc = 0.f;
+    long long qsum = 0;                      // the same fixed-point terms as pass 1: the bucket order (claimed by atomics) does not matter
     for (uint32_t j = lane; j < n; j += 64) {
       const unsigned long long k = keys[j];
       if (k > prefix) continue;
       const int64_t i = (int64_t)(uint32_t)k;
       const float dx = xf - xy[i * 2], dy = yf - xy[i * 2 + 1];
-      acc += __logf(1.0f - fminf(1.0f - (dx * dx + dy * dy) / r2, kAlphaMax));
+      qsum += ps_quantise(dx * dx + dy * dy, r2, scale);
     }
-    acc = wave_sum_f32(acc);
+    qsum = wave_sum_i64(qsum);
+    const float acc = (float)qsum / scale;
     if (lane == 0) { thresh[o] = prefix; logT[o] = acc; mask[o] = 1.0f - __expf(acc); }
   }
 }
@@ -199,7 +227,7 @@ __global__ __launch_bounds__(256) void ps_backward(const float* __restrict__ xy,
   }
 }
 
-struct PsLayout { int64_t npix, cap; size_t count, logT, thresh, slot_of, over, over_pix, over_off, fill, bucket, total; };
+struct PsLayout { int64_t npix, cap; size_t acc, count, logT, thresh, slot_of, over, over_pix, over_off, fill, bucket, total; };
 PsLayout ps_layout(int64_t nimg, int64_t V, int32_t H, int32_t W, float radius) {
   PsLayout L;
   L.npix = nimg * H * W;
@@ -207,7 +235,7 @@ PsLayout ps_layout(int64_t nimg, int64_t V, int32_t H, int32_t W, float radius) 
   L.cap = nimg * V * bx * by;                 // every pair a point can form: the buckets can never overflow
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
-  L.thresh = take((size_t)L.npix * 8); L.logT = take((size_t)L.npix * 4); L.count = take((size_t)L.npix * 4);
+  L.thresh = take((size_t)L.npix * 8); L.logT = take((size_t)L.npix * 4); L.count = take((size_t)L.npix * 4); L.acc = take((size_t)L.npix * 8);
   L.slot_of = take((size_t)L.npix * 4); L.over = take(16); L.over_pix = take((size_t)L.npix * 8); L.over_off = take((size_t)L.npix * 8);
   L.fill = take((size_t)L.npix * 4); L.bucket = take((size_t)L.cap * 8);
   L.total = o;
@@ -223,14 +251,17 @@ int64_t sr_points_silhouette_workspace_bytes(int64_t nimg, int64_t pts_per_img, 
 
 int sr_points_silhouette_fwd(const float* xy_ndc, const float* z, int64_t nimg, int64_t pts_per_img, int32_t H, int32_t W, float radius,
                              int32_t K, float* mask, void* workspace, void* stream) {
-  if (nimg < 0 || pts_per_img < 0 || H <= 0 || W <= 0 || !(radius > 0.f) || K <= 0 || nimg * pts_per_img >= ((int64_t)1 << 32)) return SR_EINVAL;
+  if (nimg < 0 || pts_per_img < 0 || H <= 0 || W <= 0 || !(radius > 0.f) || K <= 0 || K > (1 << 16) || nimg * pts_per_img >= ((int64_t)1 << 32)) return SR_EINVAL;
+  if (pts_per_img >= ((int64_t)1 << kCountBits)) return SR_EINVAL;     // the per-pixel pair count shares a word with the fixed-point sum
   if (nimg == 0) return SR_OK;
   if (!mask || !workspace || ((uintptr_t)workspace & 255) || (pts_per_img > 0 && (!xy_ndc || !z))) return SR_EINVAL;
   const PsLayout L = ps_layout(nimg, pts_per_img, H, W, radius);
   char* ws = (char*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  // zero: logT, count, slot_of (overwritten), over counters ... fill: one memset over the contiguous head, buckets untouched
+  // zero: packed accumulators, over counters ... fill: one memset over the contiguous head, buckets untouched
   if (hipMemsetAsync(ws + L.logT, 0, L.bucket - L.logT, st) != hipSuccess) return SR_ELAUNCH;
+  const float scale = (float)(1ll << ps_frac_bits(K));
+  unsigned long long* acc = (unsigned long long*)(ws + L.acc);
   const int64_t npts = nimg * pts_per_img;
   uint32_t* count = (uint32_t*)(ws + L.count); float* logT = (float*)(ws + L.logT);
   unsigned long long* thresh = (unsigned long long*)(ws + L.thresh); int32_t* slot_of = (int32_t*)(ws + L.slot_of);
@@ -238,11 +269,11 @@ int sr_points_silhouette_fwd(const float* xy_ndc, const float* z, int64_t nimg, 
   int64_t* over_off = (int64_t*)(ws + L.over_off); uint32_t* fill = (uint32_t*)(ws + L.fill);
   unsigned long long* bucket = (unsigned long long*)(ws + L.bucket);
   if (npts > 0)
-    hipLaunchKernelGGL(ps_accumulate, dim3(sr_stream_grid(npts, 256)), dim3(256), 0, st, xy_ndc, z, npts, pts_per_img, H, W, radius, count, logT);
-  hipLaunchKernelGGL(ps_resolve, dim3(sr_stream_grid(L.npix, 256)), dim3(256), 0, st, L.npix, K, count, logT, mask, thresh, slot_of, over, over_pix, over_off);
+    hipLaunchKernelGGL(ps_accumulate, dim3(sr_stream_grid(npts, 256)), dim3(256), 0, st, xy_ndc, z, npts, pts_per_img, H, W, radius, scale, acc);
+  hipLaunchKernelGGL(ps_resolve, dim3(sr_stream_grid(L.npix, 256)), dim3(256), 0, st, L.npix, K, 1.0f / scale, acc, count, logT, mask, thresh, slot_of, over, over_pix, over_off);
   if (npts > 0) {
     hipLaunchKernelGGL(ps_gather, dim3(sr_stream_grid(npts, 256)), dim3(256), 0, st, xy_ndc, z, npts, pts_per_img, H, W, radius, slot_of, over, over_off, fill, bucket);
-    hipLaunchKernelGGL(ps_select, dim3(512), dim3(256), 0, st, xy_ndc, H, W, radius, K, count, over, over_pix, over_off, bucket, mask, logT, thresh);
+    hipLaunchKernelGGL(ps_select, dim3(512), dim3(256), 0, st, xy_ndc, H, W, radius, K, scale, count, over, over_pix, over_off, bucket, mask, logT, thresh);
   }
   return sr_launch_status();
 }

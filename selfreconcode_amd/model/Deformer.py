@@ -319,10 +319,11 @@ class LBSkinner(nn.Module):
             a.bmin[i], a.bmax[i] = box[0][i], box[1][i]
         yb = ybar.contiguous().float()
         pbar = torch.empty_like(flat) if need_p else None
-        Abar = torch.zeros((A.shape[0], 24, 12), device=flat.device) if need_A else None
-        tbar = torch.zeros((A.shape[0], 3), device=flat.device) if need_t else None
+        Abar = torch.empty((A.shape[0], 24, 12), device=flat.device) if need_A else None            # written, not accumulated
+        tbar = torch.empty((A.shape[0], 3), device=flat.device) if need_t else None
+        part = torch.empty((max(int(_lib.raw("sr_lbs_bwd_workspace_floats")(P, A.shape[0])), 1),), device=flat.device)
         with torch.cuda.device(flat.device):
-            _lib.call("sr_lbs_bwd", ctypes.byref(a), _lib.ptr(yb), _lib.ptr(pbar), _lib.ptr(Abar), _lib.ptr(tbar), _lib.stream_of(flat))
+            _lib.call("sr_lbs_bwd", ctypes.byref(a), _lib.ptr(yb), _lib.ptr(pbar), _lib.ptr(Abar), _lib.ptr(tbar), _lib.ptr(part), _lib.stream_of(flat))
         return pbar, Abar, tbar
 
 
@@ -421,10 +422,12 @@ class _LBSValueJacobian(torch.autograd.Function):
         yb = None if ybar is None else ybar.contiguous().float()
         Jb = torch.zeros((P, 3, 3), device=flat.device) if Jbar is None else Jbar.contiguous().float()
         qbar = torch.empty_like(flat) if need_q else None
-        Abar = torch.zeros((A.shape[0], 24, 12), device=flat.device) if need_A else None
-        tbar = torch.zeros((A.shape[0], 3), device=flat.device) if (need_t and yb is not None) else None
+        Abar = torch.empty((A.shape[0], 24, 12), device=flat.device) if need_A else None            # written, not accumulated
+        tbar = torch.empty((A.shape[0], 3), device=flat.device) if (need_t and yb is not None) else None
+        part = torch.empty((max(int(_lib.raw("sr_lbs_bwd_workspace_floats")(P, A.shape[0])), 1),), device=flat.device)
         with torch.cuda.device(flat.device):
-            _lib.call("sr_lbs_jac_bwd", ctypes.byref(a), _lib.ptr(yb), _lib.ptr(Jb), _lib.ptr(qbar), _lib.ptr(Abar), _lib.ptr(tbar), _lib.stream_of(flat))
+            _lib.call("sr_lbs_jac_bwd", ctypes.byref(a), _lib.ptr(yb), _lib.ptr(Jb), _lib.ptr(qbar), _lib.ptr(Abar), _lib.ptr(tbar), _lib.ptr(part),
+                      _lib.stream_of(flat))
         if Abar is not None:
             Abar = torch.nn.functional.pad(Abar.view(A.shape[0], 24, 3, 4), (0, 0, 0, 1))
         return None, qbar, Abar, tbar, None, None

@@ -22,3 +22,44 @@ def test_two_ranks_on_one_gpu_run_the_real_step():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0 and rec["remesh"]["in_window"] == 1
+
+
+def test_plain_bench_invocation_spawns_its_ranks():
+    """`python bench.py --gpus 2` with NO launcher (the form the driver uses for --gpus 1): bench.py re-executes itself through
+    torch.distributed.run; on this 1-GPU box both ranks share device 0 (functional run).  configs[2] shape: one frame per rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames-per-gpu", "1", "--steps", "2", "--warmup", "1", "--settle", "2", "--settle-low", "1",
+           "--noise-observations", "--no-cpu-baseline", "--no-gemm-events"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["frames_per_gpu"] == 1 and rec["config"]["frames_per_step_all_ranks"] == 2
+    assert abs(rec["value"] - rec["config"]["frames_per_s"] / 3.0) < 1e-3 * rec["value"]          # reference iterations = frames / 3 (coarse batch size)
+
+
+def test_two_ranks_x_one_frame_equal_one_rank_x_two_frames(tmp_path):
+    """SURVEY.md 8(e) caveats A/B on the REAL step: the template SGD step and every gradient after the all-reduce of two ranks with
+    one frame each equal those of one rank with the two-frame batch (see tests/_dist_equiv_worker.py for what is compared and why)."""
+    import numpy as np
+    worker = os.path.join(ROOT, "tests", "_dist_equiv_worker.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    r = subprocess.run([sys.executable, worker, "--out", one], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env2 = dict(env, SR_ALL_RANKS_ON_DEVICE0="1", SR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29579",
+                        worker, "--out", two, "--inject", one], env=env2, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = np.load(one), np.load(two)
+    assert int(a["nrays"]) > 500 and int(a["nconv"]) > 100
+    np.testing.assert_allclose(b["TmpVs"], a["TmpVs"], rtol=0, atol=2e-7)              # the shared template takes the SAME step (caveat A)
+    bad = []
+    for k in a.files:
+        if not k.startswith("g_"):
+            continue
+        assert k in b.files, k
+        err = np.abs(a[k] - b[k]).max() / max(np.abs(a[k]).max(), 1e-30)
+        l2 = np.linalg.norm(a[k] - b[k]) / max(np.linalg.norm(a[k]), 1e-30)
+        if err > 1e-4 or l2 > 1e-4:
+            bad.append((k, float(err), float(l2)))
+    assert not bad, bad

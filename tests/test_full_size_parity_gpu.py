@@ -65,6 +65,41 @@ class Report:
         assert not self.bad, "\n".join(self.bad)
 
 
+def l1_sign_correction(net, f_ref, weight, ratio, max_frac=0.01):
+    """The template term  weight * mean |f(TmpVs)|  (network.py:690-694) has the gradient  (weight / V) sum_i sign(f_i) df_i/dtheta.  After
+    the template step thousands of vertices sit within ~1e-5 of the zero set, where sign(f_i) is decided by the last bits of f -- in
+    the reference as much as here.  So the two sides are compared in two parts:
+      * f itself at every moved vertex (absolute tolerance 1e-5: the float32 evaluation error of f plus the 3e-3 relative agreement
+        of the template step), and the vertices whose SIGN differs must all be such near-zero ones and few;
+      * the SDF parameter gradients after the contribution of exactly those vertices has been moved to the reference's sign:
+        returns {parameter name: correction} = d/dtheta [(weight / V) sum_{i in D} (s_ref - s_prod)_i f_i]  (plain autograd through the
+        product's SDF), to be ADDED to the product's gradient."""
+    from selfreconcode_amd import mlp_engine
+    assert not mlp_engine.DEFERRED_PARAM_GRADS
+    V = net.TmpVs.shape[0]
+    with torch.no_grad():
+        f_prod = net.sdf(net.TmpVs.detach(), ratio, sdf_only=True).view(-1)
+    f_ref = f_ref.to(f_prod.device).float().view(-1)
+    assert float((f_prod - f_ref).abs().max()) < 1e-5 + 2e-3 * float(f_ref.abs().max()), float((f_prod - f_ref).abs().max())
+    D = ((f_prod > 0) != (f_ref > 0)).nonzero().view(-1)
+    stats = (int(D.numel()), float(f_prod[D].abs().max()) if D.numel() else 0.0)
+    assert D.numel() <= max_frac * V and stats[1] < 3e-5, stats
+    saved = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.sdf.named_parameters()}
+    corr = {n: torch.zeros_like(p) for n, p in net.sdf.named_parameters()}
+    if D.numel():
+        for p in net.sdf.parameters():
+            p.grad = None
+        s_diff = torch.sign(f_ref[D]) - torch.sign(f_prod[D])
+        c = (float(weight) / V) * (s_diff * net.sdf(net.TmpVs.detach()[D], ratio, sdf_only=True).view(-1)).sum()
+        c.backward()
+        for n, p in net.sdf.named_parameters():
+            if p.grad is not None:
+                corr[n] = p.grad.clone()
+    for n, p in net.sdf.named_parameters():
+        p.grad = saved[n]
+    return corr, stats
+
+
 def slice_of(t):
     return t[::29, ::7] if (t.dim() == 2 and t.shape[1] > 1) else t.reshape(-1)[::5]
 
@@ -166,7 +201,12 @@ def test_full_size_iteration_vs_the_references_own_run(golden, stage):
     both = ok.cpu() & ref_ok
     assert int(both.sum()) > 1000
     dev_p = (p1.cpu()[both] - g["sel_p1"][both]).abs().amax(1)
-    assert float((dev_p < 2e-5).float().mean()) > 0.9 and float(dev_p.max()) < 5e-4, (float((dev_p < 2e-5).float().mean()), float(dev_p.max()))
+    # ~3.5k rays accepted on both sides.  Where both accept, |f| < 5e-5 and the angle test hold at both points, but a ray that grazes
+    # the surface has an ill-conditioned intersection: a handful of the thousands sit up to ~1e-3 apart ALONG the ray (the miniature
+    # fixture has ~100 rays and no such tail).  So: >= 90 % within 2e-5 (the miniature bound), >= 99.5 % within 5e-4, none beyond 5e-3.
+    frac = lambda t: float((dev_p < t).float().mean())
+    assert frac(2e-5) > 0.9 and frac(5e-4) > 0.995 and float(dev_p.max()) < 5e-3, (frac(2e-5), frac(5e-4), float(dev_p.max()))
+    print("refiner vs reference: flags equal %.4f, points < 2e-5: %.4f, < 5e-4: %.4f, max %.2e" % (float((ok.cpu() == ref_ok).float().mean()), frac(2e-5), frac(5e-4), float(dev_p.max())))
 
     # (b) the whole iteration with the reference's draws and the reference's refiner output
     rand['refined'] = (g["sel_p1"], ref_ok)
@@ -193,6 +233,8 @@ def test_full_size_iteration_vs_the_references_own_run(golden, stage):
     finally:
         mlp_engine.set_deferred_param_grads(False)
     assert int(net.info['invInfo'][0]) == int(g["inv_info"][0]) and abs(int(net.info['invInfo'][1]) - int(g["inv_info"][1])) <= 2
+    corr, flips = l1_sign_correction(net, g["f_moved_x1024"].float() / 1024., float(g["pc_weight"]), RATIO)
+    print("template L1 term: %d of %d vertices change sign against the reference (largest |f| among them %.1e)" % (flips[0], V0.shape[0], flips[1]))
     tol = dict(frac=4e-3, rl2=4e-3)
     rep.cmp(ds.poses.grad, g["g_poses"], name="poses", **tol); rep.cmp(ds.trans.grad, g["g_trans"], name="trans", **tol)
     rep.cmp(ds.conds[0].grad, g["g_dcond"], name="dcond", **tol)
@@ -202,8 +244,9 @@ def test_full_size_iteration_vs_the_references_own_run(golden, stage):
     for tag, mod in (("sdf", sdf), ("tr", tr), ("rn", rn)):
         for k, (name, p) in enumerate(mod.named_parameters()):
             assert p.grad is not None, (tag, name)
-            rep.digest(p.grad, g[f"d_{tag}.{name}"], 100 * k, 4e-3, f"{tag}.{name} (whole)")
-            rep.cmp(slice_of(p.grad), g[f"s_{tag}.{name}"], 4e-3, 6e-3, f"{tag}.{name} (slice)")
+            grad = p.grad + corr[name] if tag == "sdf" else p.grad
+            rep.digest(grad, g[f"d_{tag}.{name}"], 100 * k, 4e-3, f"{tag}.{name} (whole)")
+            rep.cmp(slice_of(grad), g[f"s_{tag}.{name}"], 4e-3, 6e-3, f"{tag}.{name} (slice)")
     assert ds.conds[1].grad is None or float(ds.conds[1].grad.abs().max()) == 0.0
     print({k: tuple(round(x, 6) for x in v) for k, v in rep.worst.items()})
     rep.finish()
@@ -231,14 +274,16 @@ def _rand(big=400000):
             'regu_local': fx.det_normal((20000, 3), 46)}
 
 
-def _oracle_scene(net, ds, H, W):
-    cp = lambda sd: {k: v.detach().cpu().clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point}
+def _oracle_scene(net, ds, H, W, dtype=torch.float64):
+    """The product's weights and data handed to the CPU oracle in `dtype` (float64: the same float32 values, evaluated without float32
+    rounding -- the product's deviation from it is the product's own error, not the sum of two)."""
+    cp = lambda sd: {k: v.detach().cpu().to(dtype).clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point}
     skin = net.deformer.defs[1]
-    sk = dict(ws=skin.ws.detach().cpu().contiguous(), b_min=skin.b_min.cpu().view(3), b_max=skin.b_max.cpu().view(3), Js=skin.Js.cpu(),
-              init_pose=skin.init_pose.cpu())
-    leaf = lambda t: t.detach().cpu().clone().requires_grad_(True)
-    q = ds.camera_params['cam2world_coord_quat'].detach().cpu().view(1, 4)
-    camleaf = lambda t: t.detach().cpu().clone().requires_grad_(t.requires_grad)
+    sk = dict(ws=skin.ws.detach().cpu().to(dtype).contiguous(), b_min=skin.b_min.cpu().to(dtype).view(3), b_max=skin.b_max.cpu().to(dtype).view(3),
+              Js=skin.Js.cpu().to(dtype), init_pose=skin.init_pose.cpu().to(dtype))
+    leaf = lambda t: t.detach().cpu().to(dtype).clone().requires_grad_(True)
+    q = ds.camera_params['cam2world_coord_quat'].detach().cpu().to(dtype).view(1, 4)
+    camleaf = lambda t: t.detach().cpu().to(dtype).clone().requires_grad_(t.requires_grad)
     cam = dict(focal=camleaf(ds.camera_params['focal_length']), princ=camleaf(ds.camera_params['princeple_points']), R=orc.quat2mat(q)[0],
                T=camleaf(ds.camera_params['world2cam_coord_trans']), H=H, W=W)
     return ito.Scene(cp(net.sdf.state_dict()), cp(dict(net.deformer.defs[0].state_dict())), cp(net.netRender.state_dict()), sk, leaf(ds.poses), leaf(ds.trans),
@@ -246,9 +291,9 @@ def _oracle_scene(net, ds, H, W):
 
 
 def test_full_size_bench_scene_iteration_vs_cpu_oracle():
-    """(2): 3 frames x 2048 rays on the 540 x 540 bench scene, float32 on both sides; the refiner's output is injected from the
-    product into the oracle for the terms after it (its acceptance test flips on single ulps; (1) and tests/test_refiner_gpu.py
-    compare the refiner itself)."""
+    """(2): 3 frames x 2048 rays on the 540 x 540 bench scene against the CPU oracle evaluated in float64 on the same float32 inputs; the
+    refiner's output is injected from the product into the oracle for the terms after it (its acceptance test flips on single ulps;
+    (1) and tests/test_refiner_gpu.py compare the refiner itself)."""
     import time
     from selfreconcode_amd import mlp_engine
     mlp_engine.set_deferred_param_grads(True)
@@ -271,12 +316,13 @@ def test_full_size_bench_scene_iteration_vs_cpu_oracle():
         assert 5500 < nsel < 6800 and nconv > 0.3 * nsel, (nsel, nconv)
         # ---- oracle
         t0 = time.perf_counter()
-        TmpVs_o = V0.cpu().clone().requires_grad_(True)
+        TmpVs_o = V0.cpu().double().clone().requires_grad_(True)
         opt_o = torch.optim.SGD([TmpVs_o], lr=0.05, momentum=0.9)
-        do = {k: v.cpu() for k, v in datas.items()}
+        do = {k: v.cpu().double() for k, v in datas.items()}
         F = ds.frame_num
         bf = lambda f, n: ((f - n // 2).clamp(min=0, max=F - n)).view(-1, 1) + torch.arange(n).view(1, n)
-        tot, info, st = ito.forward(sc, TmpVs_o, net.Tmpfs.cpu(), opt_o, do, SP, RATIO, fo, rand, dctnull=net.dctnull.cpu(), batchframe=bf,
+        tot, info, st = ito.forward(sc, TmpVs_o, net.Tmpfs.cpu(), opt_o, do, SP, RATIO, fo, {k: v.double() for k, v in rand.items()},
+                                    dctnull=net.dctnull.cpu().double(), batchframe=bf,
                                     inject={'initTmpPs': dbg['initTmpPs'].cpu(), 'check': dbg['check'].cpu()})
         rep = Report()
         assert torch.equal(info['bi'], dbg['batch_inds'].cpu()) and torch.equal(info['rows'], dbg['row_inds'].cpu()) and torch.equal(info['cols'], dbg['col_inds'].cpu())
@@ -285,18 +331,23 @@ def test_full_size_bench_scene_iteration_vs_cpu_oracle():
         for k, v in (('mask_loss', i['pc_loss']['mask_loss']), ('defconst_loss', i['pc_loss']['defconst_loss']), ('grad_loss', i['grad_loss']),
                      ('def_loss', i['def_loss']), ('dct_loss', i['dct_loss']), ('color_loss', i['color_loss']), ('normal_loss', i['normal_loss'])):
             rep.cmp(v, info[k], 2e-4, 2e-4, k)
-        torch.testing.assert_close(i['pc_loss_sdf'].cpu(), info['pc_loss_sdf'], rtol=2e-4, atol=2e-6)
+        torch.testing.assert_close(i['pc_loss_sdf'].cpu().double(), info['pc_loss_sdf'], rtol=2e-4, atol=2e-6)
         rep.cmp(loss, tot, 2e-4, 2e-4, "total loss")
         tot.backward()
         n_sys, n_ok = ito.propagate(sc, st, fo, RATIO)
-        print("full-size CPU oracle iteration: %.1f s" % (time.perf_counter() - t0))
+        print("full-size CPU oracle iteration (float64): %.1f s" % (time.perf_counter() - t0))
         assert int(net.info['invInfo'][0]) == n_sys and abs(int(net.info['invInfo'][1]) - n_ok) <= 2
         rep.cmp(net.TmpVs.detach() - V0, TmpVs_o.detach() - V0.cpu(), 3e-3, 3e-3, "template step")
         rep.cmp(net.TmpPs.grad, st['TmpPs'].grad, 2e-3, 2e-3, "dL/dTmpPs")
+        mlp_engine.set_deferred_param_grads(False)
+        # the marching-cubes template sits ON the zero set: after the template step |f| is ~1e-6 at most vertices and sign(f) -- the
+        # gradient of the L1 term -- is a coin toss there, on both sides; see l1_sign_correction
+        corr, flips = l1_sign_correction(net, info['tmpl_pred'], net.conf.get_float('pc_weight.weight'), RATIO, max_frac=0.05)
+        print("template L1 term: %d of %d vertices change sign against the oracle (largest |f| among them %.1e)" % (flips[0], V, flips[1]))
         for mod, sd, tag in ((net.sdf, sc.sdf, "sdf"), (net.deformer.defs[0], sc.tr, "deformer"), (net.netRender, sc.rnd, "render")):
             for n, p in mod.named_parameters():
                 assert p.grad is not None, tag + " " + n
-                rep.cmp(p.grad, sd[n].grad, 3e-3, 3e-3, tag + " " + n)
+                rep.cmp(p.grad + corr[n] if tag == "sdf" else p.grad, sd[n].grad, 3e-3, 3e-3, tag + " " + n)
         rep.cmp(ds.poses.grad, sc.poses.grad, 3e-3, 3e-3, "poses"); rep.cmp(ds.trans.grad[fids], sc.trans.grad[fo], 3e-3, 3e-3, "trans")
         rep.cmp(ds.conds[0].grad[fids], sc.dcond.grad[fo], 3e-3, 3e-3, "d_cond")
         for key, okey in (('focal_length', 'focal'), ('princeple_points', 'princ'), ('world2cam_coord_trans', 'T')):

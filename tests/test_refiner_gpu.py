@@ -124,7 +124,8 @@ def test_device_driven_refiner_equals_the_layerwise_loop(P, times):
     dev_ = (pb[same] - pa[same]).abs().max(dim=1).values
     assert int((dev_ >= 5e-6).sum()) <= max(4, int(0.03 * P)) and float(dev_.max()) < 5e-3, (int((dev_ >= 5e-6).sum()), dev_.max())
     # the queue really shrinks: live counts per phase (device memory, read back here only)
-    ws = [w for (dev, cap), w in F._WORKSPACES.items() if cap == (P + 1023) // 1024 * 1024][0]
+    ws = F._WORKSPACES[(torch.device(DEV), torch.cuda.current_stream(torch.device(DEV)).cuda_stream)]      # the workspace of this (device, stream)
+    assert ws.cap >= P
     live = ws.live[:times + 2].cpu().tolist()
     assert live[0] == P and all(a >= b for a, b in zip(live, live[1:]))
     assert 0.15 * P < P - live[1] < 0.6 * P                                   # the on-surface quarter is retired by the initial test
