@@ -180,6 +180,41 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
     return rec
 
 
+def cpu_baseline_record(args, device):
+    """`cpu_baseline`: the CPU oracle (checker-side code -- this leg is the only place bench.py touches oracle/) timed on THIS box's host
+    cores on ONE whole iteration at the size of the timed workload (measured, not extrapolated), on a freshly built scene of the same
+    configuration; beside it the figure of the REFERENCE'S OWN modules at the same size, measured in the build container by
+    oracle/gen_fullsize_golden.py --time (profiles/r03_cpu_reference.json: the reference tree does not exist on the GPU box)."""
+    from oracle.cpu_baseline import full_iteration_seconds
+    from selfreconcode_amd.synthetic import build_synthetic_scene
+    FR, RAYS = frames_per_rank(args.stage, args, 1), STAGES[args.stage]["rays"]
+    net, ds, conf = build_synthetic_scene(device=device, frame_num=64, stage=args.stage, consistent_masks=False)
+    ratio = {'sdfRatio': 1., 'deformerRatio': 0.5, 'renderRatio': 1.}
+    with torch.no_grad():
+        net.angThred = net._cameras(FR, device)[0].angThreshold(0.5)
+        net.TmpVs, net.Tmpfs = net.discretizeSDF(ratio, None, 0.0)
+    fids = torch.arange(FR, device=device)
+    sec, sec_raster, threads, info = full_iteration_seconds(net, ds, fids, RAYS, ratio)
+    rec = {"value": round(1.0 / (sec - sec_raster), 5), "unit": "iterations/s", "cores": threads, "kind": "port",
+           "sample": f"ONE whole iteration of the CPU oracle (restated reference PyTorch path: forward + backward + propagateTmpPsGrad, its own refiner) at the "
+                     f"full size of the timed workload ({FR} frame(s) x {RAYS} rays, {info['template_vertices']} template vertices, 540x540, 65x225x129 volume), "
+                     f"float32, {threads} torch threads, no warm-up; the numpy restatement of the third-party rasterisers ({sec_raster:.1f} s) is excluded; remesh excluded",
+           "seconds_per_iteration": round(sec - sec_raster, 3), "seconds_rasteriser_restatement": round(sec_raster, 3), **info}
+    ref = os.path.join(ROOT, "profiles", "r03_cpu_reference.json")
+    if os.path.isfile(ref):
+        with open(ref) as fh:
+            r = json.load(fh)
+        st = [x for x in r["stages"] if x["stage"] == args.stage]
+        if st:
+            rec["reference_modules"] = {"kind": "reference", "where": r["where"], "cores": r["cores"], "dtype": r.get("dtype", "f32"), "value": st[0]["iterations_per_s"],
+                                        "unit": "iterations/s", "seconds_per_iteration": st[0]["seconds_per_iteration"], "protocol": r["protocol"],
+                                        "note": "the reference's OWN modules (model/network.py:451-814) at the same size, timed in the build container (profiles/r03_cpu_reference.json); "
+                                                "the reference tree does not travel to the GPU box"}
+    del net, ds
+    gc.collect(); torch.cuda.empty_cache()
+    return rec
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: re-execute through torch.distributed.run, one rank per GPU, same arguments."""
     import socket
@@ -319,12 +354,7 @@ def main():
         with open(args.shape_log, "w") as fh:
             json.dump(shapes, fh, indent=1)
     if world == 1 and not args.no_cpu_baseline:
-        from oracle.cpu_baseline import estimate_iteration_seconds       # checker-side code, baseline leg only
-        sec, parts, threads = estimate_iteration_seconds(V, main_rec["rays_per_iter"], FR, conv_frac=main_rec["rays_converged_frac"])
-        out["cpu_baseline"] = {"value": round(1.0 / sec, 5), "unit": "iterations/s", "cores": threads, "kind": "port",
-                               "sample": "CPU oracle (restated reference PyTorch path, NOT the reference's own modules) timed per loss term on 1024-point / "
-                                         "256-ray samples, scaled linearly to this run's point counts; rasterisation + remesh excluded",
-                               "seconds_per_iteration": round(sec, 3), "parts_s": {k: round(v, 3) for k, v in parts.items()}}
+        out["cpu_baseline"] = cpu_baseline_record(args, device)
     print(json.dumps(out), flush=True)
 
 

@@ -324,6 +324,11 @@ int sr_svd3x3(const float* A, int64_t n, float* U, float* S, float* V, void* str
  * (primal, tangent) row interleave of the group-2 GEMMs); a NULL source gives zero rows. */
 int sr_rows_pad(const float* a, int64_t lda, int32_t na, const float* b, int64_t ldb, int32_t nb, int64_t rows, int32_t group, float* dst, int64_t ldd,
                 int32_t width, void* stream);
+/* out [n,E] = per-frame sums of the rows of X [P, ldx >= E]: out[f] = sum_{index[r] == f} X[r, :E]  (n <= 32) -- the backward of the
+ * per-frame code gather conds[batch_inds] (model/Deformer.py:61,75), deterministic (fixed-order folds; torch's index_add uses float
+ * atomics).  `partial`: sr_rows_frame_sum_workspace_floats(P, E, n) floats of scratch. */
+int64_t sr_rows_frame_sum_workspace_floats(int64_t P, int32_t E, int32_t n);
+int sr_rows_frame_sum(const float* X, int64_t ldx, int64_t P, int32_t E, const int64_t* index, int32_t n, float* partial, float* out, void* stream);
 
 #define SR_PACK_MAX_LAYERS 16
 typedef struct { const float* v; const float* g; float* W; float* WT; float* norms; int32_t N, K; int64_t ldw, ldwt; } sr_pack_layer;

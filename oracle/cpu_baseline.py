@@ -101,3 +101,56 @@ def estimate_iteration_seconds(V, P, N, conv_frac=0.5, tracer_iters=6.0, sample=
     parts['color_normal_propagate'] = _t(cn) * (P * conv_frac / nc)
     total = sum(parts.values())
     return total, parts, threads
+
+
+def full_iteration_seconds(net, ds, frame_ids, sample_pix, ratio, threads=None):
+    """ONE whole iteration of the CPU oracle (oracle/iteration_oracle.py: forward + backward + propagate, its own refiner, the numpy
+    rasterisers) AT THE SIZE bench.py times, on the product's current state (weights, template, observations copied to the host), in
+    float32 -- measured, not extrapolated.  Returns (seconds, seconds of the rasteriser restatement inside it, threads, info).
+    Used only by bench.py's `cpu_baseline` leg (kind "port")."""
+    import time
+    from . import iteration_oracle as ito
+    threads = threads or min(os.cpu_count(), 32)
+    torch.set_num_threads(threads)
+    cp = lambda sd: {k: v.detach().cpu().clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point}
+    skin = net.deformer.defs[1]
+    sk = dict(ws=skin.ws.detach().cpu().contiguous(), b_min=skin.b_min.cpu().view(3), b_max=skin.b_max.cpu().view(3), Js=skin.Js.cpu(), init_pose=skin.init_pose.cpu())
+    leaf = lambda t: t.detach().cpu().clone().requires_grad_(True)
+    q = ds.camera_params['cam2world_coord_quat'].detach().cpu().view(1, 4)
+    camleaf = lambda t: t.detach().cpu().clone().requires_grad_(t.requires_grad)
+    cam = dict(focal=camleaf(ds.camera_params['focal_length']), princ=camleaf(ds.camera_params['princeple_points']), R=orc.quat2mat(q)[0],
+               T=camleaf(ds.camera_params['world2cam_coord_trans']), H=ds.H, W=ds.W)
+    sc = ito.Scene(cp(net.sdf.state_dict()), cp(dict(net.deformer.defs[0].state_dict())), cp(net.netRender.state_dict()), sk, leaf(ds.poses), leaf(ds.trans),
+                   leaf(ds.conds[0]), leaf(ds.conds[1]), cam, net.conf, net.point_radius, float(net.angThred))
+    V = net.TmpVs.shape[0]
+    TmpVs = net.TmpVs.detach().cpu().clone().requires_grad_(True)
+    opt = torch.optim.SGD([TmpVs], lr=0.05, momentum=0.9)
+    fo = frame_ids.cpu()
+    datas = {k: v.cpu() for k, v in ds.batch(frame_ids).items()}
+    g = torch.Generator().manual_seed(0)
+    big = ds.H * ds.W * int(fo.numel())
+    rand = {'ray_select': torch.rand(big, generator=g), 'vert_select': torch.rand(V, generator=g), 'vert_select2': torch.rand(V, generator=g),
+            'eik_local': torch.randn(20000, 3, generator=g), 'eik_global': torch.rand(20000, 3, generator=g), 'regu_local': torch.randn(20000, 3, generator=g)}
+    F = ds.frame_num
+    bf = lambda f, n: ((f - n // 2).clamp(min=0, max=F - n)).view(-1, 1) + torch.arange(n).view(1, n)
+    raster = {'s': 0.0}
+    real_mesh, real_pts = ito.ro.rasterize_meshes, ito.ro.rasterize_points
+
+    def timed(fn):
+        def wrapper(*a, **k):
+            t0 = time.perf_counter()
+            out = fn(*a, **k)
+            raster['s'] += time.perf_counter() - t0
+            return out
+        return wrapper
+    ito.ro.rasterize_meshes, ito.ro.rasterize_points = timed(real_mesh), timed(real_pts)
+    try:
+        t0 = time.perf_counter()
+        tot, info, st = ito.forward(sc, TmpVs, net.Tmpfs.cpu(), opt, datas, sample_pix, ratio, fo, rand, dctnull=net.dctnull.cpu(), batchframe=bf)
+        tot.backward()
+        if st is not None:
+            ito.propagate(sc, st, fo, ratio)
+        sec = time.perf_counter() - t0
+    finally:
+        ito.ro.rasterize_meshes, ito.ro.rasterize_points = real_mesh, real_pts
+    return sec, raster['s'], threads, {"rays": int(info['rays']), "rays_converged": int(info['check'].sum()), "template_vertices": int(V)}

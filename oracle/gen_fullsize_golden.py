@@ -15,9 +15,11 @@ propagateTmpPsGrad on the reference's own modules; pytorch3d renderers -> oracle
     forward runs), so the product gets the same numbers through `rand=`.
 Stored: ray selection, seeds, the refiner's output, every loss term, the total, the template step (strided), dL/dTmpPs, whole
 per-frame / camera gradients and -- for every parameter of the three networks -- its L2 norm, two fixed random projections and a
-strided slice, and f at the moved template vertices.  The fixture run evaluates the reference's modules in FLOAT64 on the same
-(float32-representable) inputs -- see build() -- so the product is held to the reference's algorithm, not to one float32 rounding of it.
-`--time` additionally writes profiles/r03_cpu_reference.json: the reference's own modules in float32, as they run, timed on this
+strided slice, and f at the moved template vertices.  The fixture is the reference as it runs, in float32.  (`--f64` evaluates the same
+modules in double on the same inputs -- see build().  Tried as the fixture and dropped: the discrete decisions of the iteration --
+which (point, pixel) pairs of the silhouette splat exist, which rays the refiner accepts -- are float32 decisions in the reference
+and here; a float64 evaluation makes MORE of them differently from the product than the float32 reference does, and a flipped pair
+moves the gradient of its vertex by a finite amount.)  `--time` additionally writes profiles/r03_cpu_reference.json: the reference's own modules in float32, as they run, timed on this
 container's cores at full size (warm-up 1, then median of 3) -- the `cpu_baseline` of kind "reference" that bench.py reports.
 """
 import json
@@ -69,10 +71,8 @@ def mask_image(N, H, W):
 
 
 def build(stage, H=540, W=540, lbs_shape=(65, 225, 129), F=40, n_cube=None, dtype=torch.float32):
-    """`dtype`: float32 = the reference as it runs (timing); float64 = the same modules, same float32-representable inputs, evaluated in
-    double (torch's default dtype is switched so that every tensor the reference creates on the way is double too): the fixture then
-    holds the reference's algorithm WITHOUT its own float32 rounding noise -- at this size several gradients are sums over 10^5
-    points with heavy cancellation, and two float32 evaluations that differ only in summation order disagree by up to 1e-2 there."""
+    """`dtype`: float32 = the reference as it runs (fixture and timing); float64 = the same modules, same float32-representable inputs,
+    evaluated in double (torch's default dtype is switched so that every tensor the reference creates on the way is double too)."""
     cfg = STAGES[stage]
     N = cfg["N"]
     n_cube = n_cube or cfg["n_cube"]
@@ -293,7 +293,7 @@ if __name__ == "__main__":
     recs = []
     for st in stages:
         if "--no-golden" not in sys.argv:
-            run(st, False, small, torch.float64)                          # the fixture: the reference's algorithm evaluated in double
+            run(st, False, small, torch.float64 if "--f64" in sys.argv else torch.float32)     # the fixture: the reference as it runs (float32)
         if "--time" in sys.argv:
             recs.append(run(st, True, small, torch.float32, write=False))    # the baseline: the reference as it runs, float32
     if "--time" in sys.argv and not small:

@@ -140,26 +140,7 @@ LOSS_COARSE = {'color_weight': 0.5, 'normal_weight': 0.1, 'weighted_normal': Tru
                'pc_weight': {'weight': 60., 'laplacian_weight': -10., 'edge_weight': -10., 'norm_weight': -0.001, 'def_consistent': {'weight': 0.6, 'c': 0.01}}}
 
 
-def icosphere(levels=2):
-    t = (1.0 + 5 ** 0.5) / 2.0
-    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
-    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8), (3, 9, 4), (3, 4, 2),
-         (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
-    v = [np.array(p, dtype=np.float64) / np.linalg.norm(p) for p in v]
-    for _ in range(levels):
-        cache, nf = {}, []
-
-        def mid(a, b):
-            key = (min(a, b), max(a, b))
-            if key not in cache:
-                m = v[a] + v[b]
-                v.append(m / np.linalg.norm(m)); cache[key] = len(v) - 1
-            return cache[key]
-        for a, b, c in f:
-            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
-            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
-        f = nf
-    return torch.tensor(np.stack(v), dtype=torch.float32), torch.tensor(f, dtype=torch.long)
+icosphere = fx.icosphere          # (shared with the GPU tests, which cannot import this module: it loads the reference)
 
 
 def main():

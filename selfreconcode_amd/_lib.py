@@ -160,6 +160,8 @@ SIGNATURES = {
     "sr_mc_count": [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp, _vp, _vp],
     "sr_mc_emit": [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _vp] + [ctypes.c_float] * 6 + [_vp, _vp, _vp],
     "sr_rows_pad": [_vp, _i64, ctypes.c_int32, _vp, _i64, ctypes.c_int32, _i64, ctypes.c_int32, _vp, _i64, ctypes.c_int32, _vp],
+    "sr_rows_frame_sum_workspace_floats": [_i64, ctypes.c_int32, ctypes.c_int32],
+    "sr_rows_frame_sum": [_vp, _i64, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _vp, _vp],
     "sr_pack_weights": [_vp, _vp],
     "sr_unpack_grads": [_vp, _vp],
     "sr_svd3x3": [_vp, _i64, _vp, _vp, _vp, _vp],
@@ -196,7 +198,7 @@ SIGNATURES = {
     "sr_pe_embed_bwd": [_vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _i64, _vp, _vp],
     "sr_pe_embed": [_vp, _i64, ctypes.c_int32, _vp, _vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _i64, _vp],
 }
-_RESTYPE = {"sr_lbs_bwd_workspace_floats": _i64, "sr_mlp_gemm_tn_workspace_floats": _i64, "sr_mc_workspace_bytes": _i64, "sr_points_silhouette_workspace_bytes": _i64}
+_RESTYPE = {"sr_rows_frame_sum_workspace_floats": _i64, "sr_lbs_bwd_workspace_floats": _i64, "sr_mlp_gemm_tn_workspace_floats": _i64, "sr_mc_workspace_bytes": _i64, "sr_points_silhouette_workspace_bytes": _i64}
 
 _fn = {}
 for _name, _args in SIGNATURES.items():

@@ -156,6 +156,45 @@ __global__ __launch_bounds__(256) void rows_pad_kernel(const float* __restrict__
     dst[row * ldd + col] = (src && col < n) ? src[r * ld + col] : 0.f;
   }
 }
+
+// out[f, c] = sum over the rows r with index[r] == f of X[r, c]   (n frames <= 32; the backward of gathering a per-frame code into
+// every row of a batch: model/Deformer.py:61,75 `conds[batch_inds]`).  torch's index_add does this with float atomics -- a result
+// that changes from run to run.  Here every thread owns one (row group, column) lane and adds its rows in program order into its own
+// LDS cell per frame; the four row groups of a workgroup, then the row slices of the grid, are folded in a fixed order (the last
+// fold in double precision): bit-reproducible.
+constexpr int kFsCols = 64, kFsGroups = 4;
+__global__ __launch_bounds__(kFsCols * kFsGroups) void rows_frame_sum_kernel(const float* __restrict__ X, int64_t ldx, int64_t P, int E,
+                                                                              const int64_t* __restrict__ index, int n, int64_t rows_per_slice,
+                                                                              float* __restrict__ partial) {
+  extern __shared__ float fs_acc[];                        // [groups][n][cols]
+  const int c = threadIdx.x % kFsCols, rg = threadIdx.x / kFsCols;
+  const int col = blockIdx.x * kFsCols + c;
+  float* mine = fs_acc + (int64_t)rg * n * kFsCols + c;
+  for (int f = 0; f < n; ++f) mine[f * kFsCols] = 0.f;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice, r1 = min(P, r0 + rows_per_slice);
+  if (col < E)
+    for (int64_t r = r0 + rg; r < r1; r += kFsGroups) {
+      const int f = (int)index[r];
+      if (f >= 0 && f < n) mine[f * kFsCols] += X[r * ldx + col];
+    }
+  __syncthreads();
+  if (rg == 0 && col < E)
+    for (int f = 0; f < n; ++f) {
+      const float* a = fs_acc + f * kFsCols + c;
+      partial[((int64_t)blockIdx.y * n + f) * E + col] = ((a[0] + a[(int64_t)n * kFsCols]) + a[(int64_t)2 * n * kFsCols]) + a[(int64_t)3 * n * kFsCols];
+    }
+}
+__global__ __launch_bounds__(256) void rows_frame_sum_finish(const float* __restrict__ partial, int slices, int64_t ne, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += (int64_t)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int b = 0; b < slices; ++b) s += (double)partial[(int64_t)b * ne + i];
+    out[i] = (float)s;
+  }
+}
+static int fs_slices(int64_t P) {
+  int64_t s = sr_cdiv(P, 512);
+  return (int)(s > 256 ? 256 : (s < 1 ? 1 : s));
+}
 }  // namespace
 
 extern "C" {
@@ -166,6 +205,21 @@ int sr_rows_pad(const float* a, int64_t lda, int32_t na, const float* b, int64_t
   if (!dst || (a && lda < na) || (b && ldb < nb)) return SR_EINVAL;
   hipLaunchKernelGGL(rows_pad_kernel, dim3(sr_stream_grid(rows * group * (int64_t)width, 256)), dim3(256), 0, (hipStream_t)stream, a, lda, na, b, ldb, nb,
                      rows, group, dst, ldd, width);
+  return sr_launch_status();
+}
+int64_t sr_rows_frame_sum_workspace_floats(int64_t P, int32_t E, int32_t n) {
+  if (P < 0 || E <= 0 || n <= 0) return SR_EINVAL;
+  return (int64_t)fs_slices(P) * n * E;
+}
+int sr_rows_frame_sum(const float* X, int64_t ldx, int64_t P, int32_t E, const int64_t* index, int32_t n, float* partial, float* out, void* stream) {
+  if (P < 0 || E <= 0 || n <= 0 || n > 32 || ldx < E || !out) return SR_EINVAL;
+  if (P == 0) return hipMemsetAsync(out, 0, sizeof(float) * n * E, (hipStream_t)stream) == hipSuccess ? SR_OK : SR_ELAUNCH;
+  if (!X || !index || !partial) return SR_EINVAL;
+  const int slices = fs_slices(P);
+  const int64_t rows_per_slice = sr_cdiv(P, slices);
+  hipLaunchKernelGGL(rows_frame_sum_kernel, dim3((unsigned)sr_cdiv(E, kFsCols), slices), dim3(kFsCols * kFsGroups), sizeof(float) * kFsGroups * n * kFsCols,
+                     (hipStream_t)stream, X, ldx, P, E, index, n, rows_per_slice, partial);
+  hipLaunchKernelGGL(rows_frame_sum_finish, dim3(sr_stream_grid((int64_t)n * E, 256)), dim3(256), 0, (hipStream_t)stream, partial, slices, (int64_t)n * E, out);
   return sr_launch_status();
 }
 int sr_pack_weights(const sr_pack_table* t, void* stream) {

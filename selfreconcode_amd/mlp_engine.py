@@ -345,6 +345,20 @@ def rows_pad(a, width, b=None, pair=False):
     return out
 
 
+def rows_frame_sum(X, index, n):
+    """[n, E] per-frame sums of the rows of X [P, E] (any row pitch), out[f] = sum of the rows with index == f -- the deterministic
+    replacement of `zeros(n, E).index_add(0, index, X)` (float atomics) for the gradient of a per-frame code gathered into every row."""
+    P, E = X.shape
+    if X.dtype != torch.float32 or X.stride(1) != 1:
+        X = X.float().contiguous()
+    index = index.contiguous()
+    out = torch.empty((n, E), dtype=torch.float32, device=X.device)
+    part = torch.empty((max(int(_lib.raw("sr_rows_frame_sum_workspace_floats")(P, E, n)), 1),), dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        _lib.call("sr_rows_frame_sum", _lib.ptr(X), X.stride(0), P, E, _lib.ptr(index), n, _lib.ptr(part), _lib.ptr(out), _lib.stream_of(X))
+    return out
+
+
 def interleave(rows):
     """[R,K] x g -> [g*R, K] with sample-major interleaving (primal, tangent_1, ...)."""
     return torch.stack(rows, dim=1).reshape(rows[0].shape[0] * len(rows), rows[0].shape[1])

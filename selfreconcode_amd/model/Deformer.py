@@ -524,7 +524,7 @@ class TranslatorValueJacobian(torch.autograd.Function):
             if ctx.segment:
                 gcond = ge.reshape(ctx.n_extra, ctx.segment, E).sum(1)
             else:
-                gcond = torch.zeros((ctx.n_extra, E), device=flat.device).index_add(0, index, ge)
+                gcond = me.rows_frame_sum(ge, index, ctx.n_extra)            # deterministic (index_add: float atomics)
         return (None, None, xbar.view(ctx.xshape), gcond, None, None, None) + tuple(dWs) + tuple(dbs)
 
 

@@ -3,6 +3,7 @@ HIP embed kernel.  Band order [x | sin f0 | cos f0 | sin f1 | ...], bands 2^k, p
 in (sin, cos) pairs from utils.annealing_weights (utils/utils.py:40-46)."""
 import torch
 from .. import _lib
+from .. import mlp_engine
 from ..mlp_engine import pad4
 
 _WCACHE = {}
@@ -83,7 +84,8 @@ class PEFunction(torch.autograd.Function):
             elif ctx.segment:                       # rows of one frame are contiguous: plain segmented sum, no atomics
                 gextra = ge.reshape(ctx.n_extra, ctx.segment, E).sum(1)
             else:
-                gextra = torch.zeros((ctx.n_extra, E), dtype=g.dtype, device=g.device).index_add(0, extra_index, ge)
+                gextra = (mlp_engine.rows_frame_sum(ge, extra_index, ctx.n_extra).to(g.dtype) if (g.is_cuda and ctx.n_extra <= 32)
+                          else torch.zeros((ctx.n_extra, E), dtype=g.dtype, device=g.device).index_add(0, extra_index, ge))
         return gx, None, None, gextra, None, None
 
 

@@ -74,6 +74,35 @@ def test_seg3d_golden_on_gpu(golden):
     assert abs(eng.spacing_x - float(g["spacing"][0])) < 1e-9 and abs(eng.bx - float(g["origin"][0])) < 1e-9
 
 
+def _ell64(g):
+    c64, a64 = g["centre"].double(), g["radii"].double()
+
+    def ell(points):                   # float32 points -> float32 values through float64 arithmetic (oracle/gen_seg3d_full_golden.py::ell)
+        c, a = c64.to(points.device).view(1, 1, 3), a64.to(points.device).view(1, 1, 3)
+        return ((((points.double() - c) / a).norm(dim=-1) - 1.0).view(1, 1, -1) * 0.25).float()
+    return ell
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_seg3d_at_the_shipped_coarse_grid_vs_the_references_own_run(golden, fused):
+    """225 x 321 x 129, five levels (train.py:29-36): tests/golden/seg3d_full.npz is the reference's Seg3dLossless._forward
+    (MCAcc/seg3d_lossless.py:233-428) run on CPU on an analytic ellipsoid.  Same number of query points (in total: the reference's
+    bookkeeping splits them over its calls differently), bit-identical sign volume (SHA-256), identical values on a strided slice --
+    with the torch upsampler and with the fused HIP upsample + candidate selection."""
+    import hashlib
+    import numpy as np
+    from selfreconcode_amd.MCAcc import Seg3dLossless
+    g = golden("seg3d_full")
+    eng = Seg3dLossless(_ell64(g), [-0.8, -1.25, -0.4], [0.8, 0.95, 0.4], [tuple(int(x) for x in r) for r in g["res"]], balance_value=0.0, use_cuda_impl=fused).to(DEV)
+    vol = eng.forward()
+    assert vol.shape == (1, 1, 129, 321, 225)
+    assert eng.stats["queries"] == int(g["nq_total"]), (eng.stats["queries"], int(g["nq_total"]))
+    sign = (vol[0, 0] > 0).cpu().numpy()
+    assert int(sign.sum()) == int(g["npos"])
+    assert hashlib.sha256(np.packbits(np.ascontiguousarray(sign).reshape(-1)).tobytes()).digest() == bytes(g["sign_sha256"].numpy().tolist())
+    torch.testing.assert_close(vol[0, 0, ::8, ::8, ::8].cpu(), g["slice"], rtol=1e-6, atol=1e-7)
+
+
 def test_discretize_sdf_mlp_extracts_a_closed_surface():
     """Seg3dLossless + fused SDF query + MC on the near-sphere network: the lossless property -- the sign of
     every voxel of the coarse-to-fine volume equals the sign of a dense evaluation."""

@@ -20,7 +20,8 @@ def _matrices(n, dtype):
     m[::7] *= 0.03                                   # |det| ~ 1e-5: below the 1e-4 threshold -> zeros + False
     m[::11, 2] = m[::11, 0] * 0.5 + m[::11, 1]       # exactly dependent rows
     m[::13] *= 0.2                                   # |det| scattered around the threshold
-    m[5] = 0.0
+    if n > 5:
+        m[5] = 0.0
     return m.astype(dtype)
 
 

@@ -365,3 +365,22 @@ def test_weight_gradient_stream_gives_bitwise_the_same_gradients():
     assert all(g is not None and torch.isfinite(g).all() for g in grads[True])
     for a, b in zip(grads[True], grads[False]):
         assert torch.equal(a, b)
+
+
+def test_rows_frame_sum_is_exact_and_reproducible():
+    """sr_rows_frame_sum (gradient of the per-frame code gather conds[batch_inds], model/Deformer.py:61,75) against float64 sums; ragged,
+    empty and unsorted frames, a padded row pitch; two calls give the same bits (torch's index_add -- float atomics -- does not)."""
+    from selfreconcode_amd import mlp_engine
+    for P, E, n, sort in ((6144, 128, 3, True), (1, 5, 1, True), (0, 7, 2, True), (3001, 130, 8, False), (70000, 128, 3, True)):
+        X = fx.det_tensor((P, E + 3), 5, 1.0).to(DEV)[:, :E]                       # row pitch E + 3
+        idx = (fx.det_tensor((P,), 6, 0.5) + 0.5).mul(n).long().clamp(max=n - 1)
+        if n > 1 and P > 10:
+            idx[idx == 1] = 0                                                      # an empty frame
+        if sort:
+            idx = idx.sort().values
+        idx = idx.to(DEV)
+        a = mlp_engine.rows_frame_sum(X, idx, n)
+        b = mlp_engine.rows_frame_sum(X, idx, n)
+        assert torch.equal(a, b)
+        want = torch.zeros(n, E, dtype=torch.float64, device=DEV).index_add(0, idx, X.double())
+        torch.testing.assert_close(a.double(), want, rtol=1e-5, atol=4e-6 * max(1.0, P / n) ** 0.5)        # float32 partial sums of ~P/n terms of size <= 1

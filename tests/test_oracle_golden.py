@@ -197,6 +197,21 @@ def test_seg3d_restatement(golden):
     close(vol[0, 0], g["vol"], rtol=0, atol=0)
 
 
+def test_seg3d_restatement_at_the_shipped_coarse_grid(golden):
+    """The oracle's Seg3dLossless restatement at 225 x 321 x 129 (train.py:29-36) against the reference's own run
+    (tests/golden/seg3d_full.npz, oracle/gen_seg3d_full_golden.py): query count, sign volume hash, values on a strided slice."""
+    import hashlib
+    g = golden("seg3d_full")
+    c64, a64 = g["centre"].double().view(1, 1, 3), g["radii"].double().view(1, 1, 3)
+    ell = lambda points: ((((points.double() - c64) / a64).norm(dim=-1) - 1.0).view(1, 1, -1) * 0.25).float()
+    st = {}
+    vol = orc.seg3d_lossless(ell, [-0.8, -1.25, -0.4], [0.8, 0.95, 0.4], [tuple(int(x) for x in r) for r in g["res"]], 0.0, stats=st)
+    assert st["queries"] == int(g["nq_total"])
+    sign = (vol[0, 0] > 0).numpy()
+    assert hashlib.sha256(np.packbits(np.ascontiguousarray(sign).reshape(-1)).tobytes()).digest() == bytes(g["sign_sha256"].numpy().tolist())
+    close(vol[0, 0, ::8, ::8, ::8], g["slice"], rtol=1e-6, atol=1e-7)      # (interpolated voxels: the order of the trilinear sums differs by an ulp)
+
+
 def test_propagate_tmp_ps_grad_vs_the_references_own_run(golden):
     """a15: oracle/iteration_oracle.py::propagate against tests/golden/propagate.npz = OptimNetwork.propagateTmpPsGrad of the reference
     run verbatim on CPU (model/network.py:702-814), with learnable focal length / principal point / T: gradients of the SDF, the
