@@ -74,7 +74,9 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
     _fsp.DEVICE_DRIVEN = args.refiner_impl == "device"
     mlp_engine.set_deferred_param_grads(True)              # one weight-norm backward + grad add per layer per step
     lr0 = conf.get_float('train.learning_rate')
-    opt = torch.optim.Adam([{'params': ds.learnable_weights()}, {'params': params}], lr=lr0)
+    from selfreconcode_amd.optim import FusedAdam          # torch.optim.Adam's update (train.py:139) in one launch per step (--torch-adam: torch's own)
+    Adam = torch.optim.Adam if args.torch_adam else FusedAdam
+    opt = Adam([{'params': ds.learnable_weights()}, {'params': params}], lr=lr0)
     bucket = srdist.GradBucket(list(ds.learnable_weights()) + params, early=list(net.netRender.parameters()) + [ds.conds[1]])
     bucket.sync_initial_state()
     ratio_of = lambda it: {'sdfRatio': 1., 'deformerRatio': min(1.0, it / 2500. + 0.5), 'renderRatio': 1.}
@@ -250,6 +252,7 @@ def main():
     ap.add_argument("--refiner-impl", choices=["device", "layerwise"], default="device", help="device-driven compacting refiner or the layer-by-layer host loop")
     ap.add_argument("--no-sdf-throughput", action="store_true", help="skip the SDF-MLP Gsamples/s leg (PMC passes: keeps the launch population = the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam (multi-tensor launches) instead of the one-launch FusedAdam")
     ap.add_argument("--no-gemm-events", action="store_true", help="skip the HIP-event pairs around the layer GEMMs (roofline leg) to see their cost")
     ap.add_argument("--shape-log", default=None, help="write the per-(M,N,K) GEMM launch table (events) to this JSON file")
     args = ap.parse_args()
@@ -313,7 +316,7 @@ def main():
                    "rays_per_iter": main_rec["rays_per_iter"], "rays_converged_frac": main_rec["rays_converged_frac"],
                    "observations": "uniform noise" if args.noise_observations else "rendered from the scene (render_frames), re-rendered after the settle phase",
                    "refiner": {"impl": args.refiner_impl, "stream_headline_pass": args.refiner_stream, "stream_instrumented_pass": "main"},
-                   "optimizer": {"lr_timed": args.lr, "settle_iters_lr_1e-4": args.settle, "settle_iters_lr_timed": args.settle_low},
+                   "optimizer": {"impl": "torch.optim.Adam" if args.torch_adam else "FusedAdam (same update rule, one launch)", "lr_timed": args.lr, "settle_iters_lr_1e-4": args.settle, "settle_iters_lr_timed": args.settle_low},
                    "rasterisation": "in-repo HIP kernels with pytorch3d 0.4.0 semantics (nearest-face mesh rasteriser -> FindSurfacePs; K=50 nearest-in-z "
                                     "point compositor); pytorch3d itself is third-party and not in the reference repository",
                    "parallelism": f"frame-parallel dp{world}: one flat grad all-reduce/step (overlapped with the implicit-gradient pass) + template-vertex grad all-reduce"},

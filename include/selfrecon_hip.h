@@ -338,6 +338,14 @@ typedef struct { int32_t nlayers; sr_unpack_layer layer[SR_PACK_MAX_LAYERS]; } s
 int sr_pack_weights(const sr_pack_table* host_table, void* stream);
 int sr_unpack_grads(const sr_unpack_table* host_table, void* stream);
 
+/* Adam step (torch.optim.Adam, weight_decay 0, amsgrad off -- the optimizer of train.py:139) of up to SR_ADAM_MAX_TENSORS contiguous
+ * float32 tensors in one launch.  Per tensor: p, g (gradient), m (exp_avg), v (exp_avg_sq), numel, lr, bias1 = 1 - beta1^step,
+ * inv_sqrt_bias2 = 1 / sqrt(1 - beta2^step) (host-side scalars of the tensor's step count). */
+#define SR_ADAM_MAX_TENSORS 64
+typedef struct { float* p; const float* g; float* m; float* v; int64_t numel; float lr, bias1, inv_sqrt_bias2, pad_; } sr_adam_tensor;
+typedef struct { int32_t ntensors; float beta1, beta2, eps; sr_adam_tensor tensor[SR_ADAM_MAX_TENSORS]; } sr_adam_table;
+int sr_adam_step(const sr_adam_table* host_table, void* stream);
+
 /* ---------------------------------------------------------------- interp2x_boundary3d (K10/K11)
  * Replaces MCAcc/cuda/interp2x_boundary3d.cpp:forward/backward -> interp2x_boundary3d_kernel.cu:11-151, 155-239
  * (compiled but never enabled in the reference: every Seg3dLossless is built with use_cuda_impl=False).

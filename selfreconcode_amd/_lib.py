@@ -85,6 +85,19 @@ class SrUnpackLayer(ctypes.Structure):
                 ("accumulate", ctypes.c_int32)]
 
 
+SR_ADAM_MAX_TENSORS = 64
+
+
+class SrAdamTensor(ctypes.Structure):
+    _fields_ = [("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("numel", _i64), ("lr", ctypes.c_float), ("bias1", ctypes.c_float),
+                ("inv_sqrt_bias2", ctypes.c_float), ("pad_", ctypes.c_float)]
+
+
+class SrAdamTable(ctypes.Structure):
+    _fields_ = [("ntensors", ctypes.c_int32), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
+                ("tensor", SrAdamTensor * SR_ADAM_MAX_TENSORS)]
+
+
 class SrUnpackTable(ctypes.Structure):
     _fields_ = [("nlayers", ctypes.c_int32), ("layer", SrUnpackLayer * SR_PACK_MAX_LAYERS)]
 
@@ -162,6 +175,7 @@ SIGNATURES = {
     "sr_rows_pad": [_vp, _i64, ctypes.c_int32, _vp, _i64, ctypes.c_int32, _i64, ctypes.c_int32, _vp, _i64, ctypes.c_int32, _vp],
     "sr_rows_frame_sum_workspace_floats": [_i64, ctypes.c_int32, ctypes.c_int32],
     "sr_rows_frame_sum": [_vp, _i64, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _vp, _vp],
+    "sr_adam_step": [_vp, _vp],
     "sr_pack_weights": [_vp, _vp],
     "sr_unpack_grads": [_vp, _vp],
     "sr_svd3x3": [_vp, _i64, _vp, _vp, _vp, _vp],

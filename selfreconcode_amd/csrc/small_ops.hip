@@ -157,6 +157,24 @@ __global__ __launch_bounds__(256) void rows_pad_kernel(const float* __restrict__
   }
 }
 
+// Adam step of up to SR_ADAM_MAX_TENSORS parameter tensors in ONE launch (torch.optim.Adam without weight decay / amsgrad, the
+// optimizer of train.py:139: m <- m + (1 - b1)(g - m);  v <- b2 v + (1 - b2) g g;  p <- p - lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)).
+// torch's multi-tensor implementation issues ~10 launches with 40 us of host time between them at the end of every iteration.
+__global__ __launch_bounds__(256) void adam_step_kernel(sr_adam_table t) {
+  const sr_adam_tensor T = t.tensor[blockIdx.y];
+  const float b1 = t.beta1, b2 = t.beta2, eps = t.eps;
+  const float step_size = T.lr / T.bias1, inv_sqrt_bias2 = T.inv_sqrt_bias2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T.numel; i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = T.g[i];
+    float m = T.m[i], v = T.v[i];
+    m = m + (g - m) * (1.0f - b1);
+    v = v * b2 + (1.0f - b2) * g * g;
+    T.m[i] = m; T.v[i] = v;
+    const float denom = sqrtf(v) * inv_sqrt_bias2 + eps;
+    T.p[i] = T.p[i] - step_size * (m / denom);
+  }
+}
+
 // out[f, c] = sum over the rows r with index[r] == f of X[r, c]   (n frames <= 32; the backward of gathering a per-frame code into
 // every row of a batch: model/Deformer.py:61,75 `conds[batch_inds]`).  torch's index_add does this with float atomics -- a result
 // that changes from run to run.  Here every thread owns one (row group, column) lane and adds its rows in program order into its own
@@ -220,6 +238,15 @@ int sr_rows_frame_sum(const float* X, int64_t ldx, int64_t P, int32_t E, const i
   hipLaunchKernelGGL(rows_frame_sum_kernel, dim3((unsigned)sr_cdiv(E, kFsCols), slices), dim3(kFsCols * kFsGroups), sizeof(float) * kFsGroups * n * kFsCols,
                      (hipStream_t)stream, X, ldx, P, E, index, n, rows_per_slice, partial);
   hipLaunchKernelGGL(rows_frame_sum_finish, dim3(sr_stream_grid((int64_t)n * E, 256)), dim3(256), 0, (hipStream_t)stream, partial, slices, (int64_t)n * E, out);
+  return sr_launch_status();
+}
+int sr_adam_step(const sr_adam_table* t, void* stream) {
+  if (!t || t->ntensors < 1 || t->ntensors > SR_ADAM_MAX_TENSORS || !(t->beta1 >= 0.f && t->beta1 < 1.f) || !(t->beta2 >= 0.f && t->beta2 < 1.f)) return SR_EINVAL;
+  for (int k = 0; k < t->ntensors; ++k) {
+    const sr_adam_tensor& T = t->tensor[k];
+    if (!T.p || !T.g || !T.m || !T.v || T.numel <= 0 || !(T.bias1 > 0.f) || !(T.inv_sqrt_bias2 > 0.f)) return SR_EINVAL;
+  }
+  hipLaunchKernelGGL(adam_step_kernel, dim3(64, t->ntensors), dim3(256), 0, (hipStream_t)stream, *t);
   return sr_launch_status();
 }
 int sr_pack_weights(const sr_pack_table* t, void* stream) {

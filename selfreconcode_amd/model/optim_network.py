@@ -87,9 +87,13 @@ class OptimNetwork(nn.Module):
             self.next_train_conf = None
 
     # ------------------------------------------------------------------ SDF pre-fit (network.py:207-290)
-    def initializeTmpSDF(self, nepochs, save_name=None, with_normals=False, verbose=False):
+    def initializeTmpSDF(self, nepochs, save_name=None, with_normals=False, verbose=False, rand=None):
         """Fits the SDF to the body template `self.tmpBodyVs` (+ `self.tmpBodyNs`): |f| on the surface, eikonal term off it,
-        optional normal alignment; Adam lr 0.005, StepLR(500, 0.5), batches of 5000 points -- the reference's schedule."""
+        optional normal alignment; Adam lr 0.005, StepLR(500, 0.5), batches of 5000 points -- the reference's schedule.
+        `rand` (extension, parity tests): object with randperm(n) / randn_like(x) / rand(n, dim), asked in the reference's call order
+        (one permutation per epoch; per batch the local noise, then the global samples of utils.sample_points).  Returns the
+        (total, manifold, eikonal, normals) losses of the last batch as device tensors; `self.prefit_history` keeps that tuple for
+        every epoch (what the reference prints per epoch, network.py:283-287)."""
         network = self.sdf
         network.train()
         optimizer = torch.optim.Adam([{"params": network.parameters(), "lr": 0.005, "weight_decay": 0}])
@@ -99,11 +103,11 @@ class OptimNetwork(nn.Module):
         with_normals = with_normals and ns is not None
         if not with_normals:
             ns = torch.ones_like(vs) / np.sqrt(3)
-        last = None
+        last, history = None, []
         for epoch in range(1, nepochs + 1):
-            perm = torch.randperm(vs.shape[0], device=vs.device)
+            perm = torch.randperm(vs.shape[0], device=vs.device) if rand is None else rand.randperm(vs.shape[0]).to(vs.device)
             for mnfld_pnts, normals in zip(torch.split(vs[perm], 5000), torch.split(ns[perm], 5000)):
-                nonmnfld_pnts = U.sample_points(mnfld_pnts, 1.8, 0.01)
+                nonmnfld_pnts = U.sample_points(mnfld_pnts, 1.8, 0.01, rand=rand)
                 mnfld_pnts = mnfld_pnts.detach().clone().requires_grad_()
                 nonmnfld_pnts.requires_grad_()
                 mnfld_pred = network(mnfld_pnts, -1)
@@ -113,18 +117,22 @@ class OptimNetwork(nn.Module):
                 mnfld_loss = mnfld_pred.abs().mean()
                 grad_loss = ((nonmnfld_grad.norm(2, dim=-1) - 1) ** 2).mean()
                 loss = mnfld_loss + 0.1 * grad_loss
+                normals_loss = torch.zeros((), device=vs.device)
                 if with_normals:
-                    loss = loss + 1.0 * ((mnfld_grad - normals.view(-1, 3)).abs()).norm(2, dim=1).mean()
+                    normals_loss = ((mnfld_grad - normals.view(-1, 3)).abs()).norm(2, dim=1).mean()
+                    loss = loss + 1.0 * normals_loss
                 optimizer.zero_grad()
                 loss.backward()
                 mlp_engine.flush_param_grads()
                 optimizer.step()
-                last = (loss.detach(), mnfld_loss.detach(), grad_loss.detach())
+                last = (loss.detach(), mnfld_loss.detach(), grad_loss.detach(), normals_loss.detach())
+            history.append(last)
             sche.step()
             if verbose and last is not None:
-                print('Train Epoch: {}\tTrain Loss: {:.6f}\tManifold loss: {:.6f}\tGrad loss: {:.6f}'.format(epoch, *[float(t) for t in last]))
+                print('Train Epoch: {}\tTrain Loss: {:.6f}\tManifold loss: {:.6f}\tGrad loss: {:.6f}\tNormals Loss: {:.6f}'.format(epoch, *[float(t) for t in last]))
         if save_name:
             torch.save(network.state_dict(), save_name)
+        self.prefit_history = history
         return last
 
     # ------------------------------------------------------------------ geometry extraction (a16 + a17)

@@ -92,12 +92,14 @@ def smpl_tmp_Apose(init_pose_type=0):
     return pose.astype(np.float32)
 
 
-def sample_points(pc_input, global_sigma, local_sigma, ratio=6):
-    """utils/utils.py:74-84."""
+def sample_points(pc_input, global_sigma, local_sigma, ratio=6, rand=None):
+    """utils/utils.py:74-84.  `rand` (extension, parity tests): object with randn_like(x) / rand(n, dim) that supplies the two draws."""
     sample_size, dim = pc_input.shape
-    sample_local = pc_input + (torch.randn_like(pc_input) * local_sigma)
+    noise = torch.randn_like(pc_input) if rand is None else rand.randn_like(pc_input)
+    sample_local = pc_input + (noise * local_sigma)
     if ratio > 0:
-        sample_global = (torch.rand(sample_size // ratio, dim, device=pc_input.device) * (global_sigma * 2)) - global_sigma
+        u = torch.rand(sample_size // ratio, dim, device=pc_input.device) if rand is None else rand.rand(sample_size // ratio, dim)
+        sample_global = (u * (global_sigma * 2)) - global_sigma
         return torch.cat([sample_local, sample_global], dim=0)
     return sample_local
 

@@ -66,7 +66,7 @@ def test_ctypes_structs_have_the_size_the_header_declares(tmp_path):
              "sr_newton_args": _lib.SrNewtonArgs, "sr_newton2_args": _lib.SrNewton2Args, "sr_chain_args": _lib.SrChainArgs,
              "sr_refine_args": _lib.SrRefineArgs, "sr_pack_layer": _lib.SrPackLayer, "sr_pack_table": _lib.SrPackTable,
              "sr_unpack_layer": _lib.SrUnpackLayer, "sr_unpack_table": _lib.SrUnpackTable, "sr_camera": _lib.SrCamera,
-             "sr_ray_pixels": _lib.SrRayPixels}
+             "sr_ray_pixels": _lib.SrRayPixels, "sr_adam_tensor": _lib.SrAdamTensor, "sr_adam_table": _lib.SrAdamTable}
     txt = open(os.path.join(ROOT, "include", "selfrecon_hip.h")).read()
     declared = set(re.findall(r"\}\s*(sr_\w+);", txt))
     assert declared == set(pairs), declared ^ set(pairs)

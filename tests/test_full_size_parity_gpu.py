@@ -352,7 +352,8 @@ def test_full_size_bench_scene_iteration_vs_cpu_oracle():
     """(2): 3 frames x 2048 rays on the 540 x 540 bench scene against the CPU oracle in float32 (the discrete float32 decisions of the
     iteration are then made alike on both sides, see oracle/gen_fullsize_golden.py); the refiner's output is injected from the
     product into the oracle for the terms after it (its acceptance test flips on single ulps; (1) and tests/test_refiner_gpu.py
-    compare the refiner itself).  Tolerances: 2e-4 on losses, 3e-3 on gradients, or 4 x the quantity's noise floor (see (1))."""
+    compare the refiner itself).  Tolerances: 2e-4 on losses, 3e-3 relative-L2 / 5e-3 of the largest entry on gradients, or 4 x the
+    quantity's noise floor (see (1))."""
     import time
     from _inject import keyed_refiner
     from selfreconcode_amd import mlp_engine
@@ -428,7 +429,7 @@ def test_full_size_bench_scene_iteration_vs_cpu_oracle():
     rep.cmp(res["g_TmpPs"], st['TmpPs'].grad, *tol("g_TmpPs", 2e-3, 2e-3), "dL/dTmpPs")
     for tag, sd in (("sdf", sc.sdf), ("tr", sc.tr), ("rn", sc.rnd)):
         for n in sd:
-            rep.cmp(res[f"{tag}.{n}"], sd[n].grad, *tol(f"{tag}.{n}", 3e-3, 3e-3), f"{tag}.{n}")
+            rep.cmp(res[f"{tag}.{n}"], sd[n].grad, *tol(f"{tag}.{n}", 5e-3, 3e-3), f"{tag}.{n}")      # (float32 on both sides)
     rep.cmp(res["poses"], sc.poses.grad, *tol("poses", 3e-3, 3e-3), "poses"); rep.cmp(res["trans"][fids], sc.trans.grad[fo], *tol("trans", 3e-3, 3e-3), "trans")
     rep.cmp(res["dcond"][fids], sc.dcond.grad[fo], *tol("dcond", 3e-3, 3e-3), "d_cond")
     for key, okey in (('focal', 'focal'), ('princ', 'princ'), ('T', 'T')):
