@@ -252,6 +252,8 @@ def main():
     ap.add_argument("--refiner-impl", choices=["device", "layerwise"], default="device", help="device-driven compacting refiner or the layer-by-layer host loop")
     ap.add_argument("--no-sdf-throughput", action="store_true", help="skip the SDF-MLP Gsamples/s leg (PMC passes: keeps the launch population = the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm", choices=["f32", "bf16x3"], default="f32", help="arithmetic of the large forward / backward-data layer GEMMs of the HEADLINE run (default: exact fp32 MFMA)")
+    ap.add_argument("--no-bf16x3-record", action="store_true", help="skip the secondary record with the split-bf16 layer GEMMs")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam (multi-tensor launches) instead of the one-launch FusedAdam")
     ap.add_argument("--no-gemm-events", action="store_true", help="skip the HIP-event pairs around the layer GEMMs (roofline leg) to see their cost")
     ap.add_argument("--shape-log", default=None, help="write the per-(M,N,K) GEMM launch table (events) to this JSON file")
@@ -264,6 +266,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
 
+    from selfreconcode_amd import mlp_engine as _me
+    _me.set_gemm_mode(args.gemm)
     main_rec = run_stage(args.stage, args, rank, world, device, args.steps, args.warmup, args.settle, args.settle_low, not args.no_gemm_events)
     net = main_rec.pop("net")
     prof, shapes = main_rec.pop("prof"), main_rec.pop("shapes")
@@ -292,6 +296,23 @@ def main():
             fine_rec.pop(k, None)
         gc.collect(); torch.cuda.empty_cache()
 
+    # secondary record: the same workload with the split-bf16 (three bf16 terms per operand, six products, fp32 accumulation) forward /
+    # backward-data layer GEMMs -- fp32-equivalent accuracy on the bf16 MFMA pipe; opt-in (SR_GEMM=bf16x3), never the headline
+    bf16x3_rec = None
+    if world == 1 and args.gemm == "f32" and not args.no_bf16x3_record:
+        _me.set_gemm_mode("bf16x3")
+        try:
+            r = run_stage(args.stage, args, rank, world, device, min(args.steps, 20), args.warmup, max(args.settle // 2, 0), args.settle_low, False)
+        finally:
+            _me.set_gemm_mode("f32")
+        for k in ("net", "prof", "shapes", "elapsed"):
+            r.pop(k, None)
+        bf16x3_rec = {"dtype": "f32-emulated-bf16x3", "ms_per_step": r["ms_per_step"], "iterations_per_s": round(1e3 / r["ms_per_step"], 4),
+                      "rays_converged_frac": r["rays_converged_frac"], "ms_per_step_remesh_amortised": r["ms_per_step_remesh_amortised"],
+                      "what": "forward / backward-data layer GEMMs with >= 8192 rows: operands split into three bf16 terms, six products accumulated in fp32 by "
+                              "v_mfma_f32_32x32x16_bf16 (error below the fp32 MFMA kernel's, tests/test_mlp_gpu.py); refiner chains, weight-gradient GEMMs and "
+                              "small launches stay exact fp32"}
+        gc.collect(); torch.cuda.empty_cache()
     if rank != 0:
         return
     FR, RAYS = main_rec["frames_per_gpu"], STAGES[args.stage]["rays"]
@@ -303,7 +324,7 @@ def main():
                   f"MultiStepLR value of epochs 80-130 of config.conf's 1e-4 schedule, see regime_lr_config for lr 1e-4)",
         "value": round(args.steps * world * FR / FR_REF / elapsed, 4), "unit": "iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_rec["ms_per_step"],
-        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32" if args.gemm == "f32" else "f32-emulated-bf16x3", "data": "synthetic",
         "config": {"workload": f"configs[1]: female-3-casual-like 540x540, {args.stage} stage, {FR} frame(s) x {RAYS} rays per rank, full iteration "
                                "(template deform + K=50 point-silhouette mask loss + template SGD, mesh rasteriser + seeds + Newton refiner, "
                                "eikonal/offset/def-regu/DCT/colour/normal, backward, implicit-grad propagation, Adam, one remesh in the timed window)",
@@ -325,6 +346,7 @@ def main():
         "refiner_ms_per_step": main_rec["refiner_ms_per_step"],
         "regime_lr_config": main_rec.get("regime_lr_config"),
         "fine_stage": fine_rec,
+        "bf16x3": bf16x3_rec,
         "sdf_mlp_gsamples_per_s": round(sdf_gs, 5),
         "hbm": hbm,
         "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel / mlp_chain_kernel (fp32 MFMA 32x32x2 layer GEMM tile code with fused epilogue; the chain kernel runs all layers of the refiner's two networks in one launch on the device-side live-ray count), EVERY launch of the timed region with >= 128 rows and > 32 columns and every chain launch; "

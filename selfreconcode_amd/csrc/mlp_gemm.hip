@@ -420,6 +420,259 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") form of the same tile, opt-in (sr_gemm_args::B3): every fp32 operand is written as the sum of three bf16
+// numbers  x = x1 + x2 + x3  (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 3 x 8 mantissa bits, exact to 2^-24) and the six
+// leading products  a1 b1 + a1 b2 + a2 b1 + a1 b3 + a3 b1 + a2 b2  are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 -- the dropped
+// terms are below 2^-24 of |a||b|, so a dot product is as accurate as the fp32 MFMA's (measured: better, the partial products are
+// exact), at 6/16 of its MFMA time: the bf16 pipe runs 16x the fp32 rate (2.46 PFLOP/s measured on this part, tools/mfma_peak.hip).
+// B (a weight matrix) arrives pre-split (three bf16 planes, sr_split_bf16x3, once per optimizer step); A (activations / cotangents) is
+// split by the thread that stages it, on its way from registers to LDS.  LDS holds bf16 planes [row][16 + 8] (48-byte pitch: the 16
+// lanes of a ds_read_b128 group hit 16 distinct 16-byte slots); a lane's fragment is 8 consecutive k of its row = one 16-byte read per
+// plane; BK = 16 per step, two LDS buffers, two register stages (tile t+2 in flight from global memory), one barrier per step in the
+// middle of the MFMA stream -- the structure of the fp32 loop above.  The accumulator layout of the 32x32 MFMAs does not depend on
+// the input type, so the epilogues are the ones above, unchanged.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BK3 = 16;           // k per step
+constexpr int P3 = BK3 + 8;       // LDS row pitch in bf16 elements (48 bytes)
+
+template <int WM, int WN, int TM, int TN>
+struct Cfg3 {
+  static constexpr int kThreads = WM * WN * 64;
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  static constexpr int kPlaneA = BM * P3, kPlaneB = BN * P3;                 // elements
+  static constexpr int kBufElems = 3 * (kPlaneA + kPlaneB);
+  static constexpr int kOperandBytes = 2 * kBufElems * 2;
+  static constexpr int kStageBytes = WM * WN * TM * 32 * (TN * 32 + 4) * 4;
+  static constexpr int kLdsBytes = kOperandBytes > kStageBytes ? kOperandBytes : kStageBytes;
+  static constexpr int kALoads = BM * (BK3 / 4) / kThreads;                   // float4 per thread and step
+  static_assert(BN * 2 == kThreads, "one 16-byte load per thread and plane");
+};
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int bf16_bits(float x) { return (unsigned int)__builtin_bit_cast(unsigned short, (__bf16)x); }
+// x -> (hi, mid, lo) bf16 bit patterns, round-to-nearest-even at every step
+__device__ __forceinline__ void split_bf16x3(float x, unsigned int& h, unsigned int& m, unsigned int& l) {
+  h = bf16_bits(x);
+  const float r1 = x - __builtin_bit_cast(float, h << 16);
+  m = bf16_bits(r1);
+  const float r2 = r1 - __builtin_bit_cast(float, m << 16);
+  l = bf16_bits(r2);
+}
+// The same for a PAIR of values, as packed dwords (low half = first value): one v_cvt_pk_bf16_f32 per plane, the packed result is what goes
+// to LDS, and its two halves are turned back into floats with a shift and a mask -- 11 VALU operations per pair.
+__device__ __forceinline__ unsigned int cvt_pk_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+__device__ __forceinline__ void split_pair_bf16x3(float a, float b, unsigned int& h, unsigned int& m, unsigned int& l) {
+  h = cvt_pk_bf16(a, b);
+  const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = cvt_pk_bf16(ra, rb);
+  l = cvt_pk_bf16(ra - __builtin_bit_cast(float, m << 16), rb - __builtin_bit_cast(float, m & 0xffff0000u));
+}
+
+template <int WM, int WN, int TM, int TN, bool KTAIL>
+__device__ __forceinline__ void gemm_nt_tile_bf16x3(const sr_gemm_args& g, int wg, unsigned char* __restrict__ smem_raw) {
+  using C_ = Cfg3<WM, WN, TM, TN>;
+  unsigned short* lds = reinterpret_cast<unsigned short*>(smem_raw);
+  auto Ap = [&](int buf, int p) -> unsigned short* { return lds + buf * C_::kBufElems + p * C_::kPlaneA; };
+  auto Bp = [&](int buf, int p) -> unsigned short* { return lds + buf * C_::kBufElems + 3 * C_::kPlaneA + p * C_::kPlaneB; };
+
+  const int tiles_n = (g.N + g.naux_fwd + C_::BN - 1) / C_::BN;
+  const int tiles_m = (g.M + C_::BM - 1) / C_::BM;
+  const int nwg = tiles_m * tiles_n;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, loc = wg / 8;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tn = wg % tiles_n, tm = wg / tiles_n;
+  const int m0 = tm * C_::BM, n0 = tn * C_::BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, kh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // ---- loaders.  A: fp32 rows (clamped into the matrix), 4 float4 per row and step.  B: one 16-byte run of a plane per thread.
+  const int nk = (g.K + BK3 - 1) / BK3;
+  // Thread -> (row, float4) maps chosen for the LDS stores (48-byte row pitch = 12 dwords, period 8 rows over the 32 store banks): the 16
+  // lanes of a ds_write_b64 group cover 8 rows x 2 adjacent float4 (8 x 4 dwords = 32 distinct banks), the 8 lanes of a ds_write_b128
+  // group 8 rows of one half (8 x 4 dwords).  (Rows x 4 float4 per 16 lanes, the natural map, is a 2-way conflict on a quarter of the
+  // banks: SQ_LDS_BANK_CONFLICT was a third of the LDS-active cycles.)
+  auto a_slot = [](int idx, int& row, int& kq) {                            // idx in [0, BM * 4)
+    const int u = idx >> 4;
+    row = ((u >> 1) << 3) | ((idx >> 1) & 7);
+    kq = (((u & 1) << 1) | (idx & 1)) * 4;
+  };
+  int arow[C_::kALoads], akq[C_::kALoads];
+  const int akmax = ((g.K + 3) & ~3) - 4;
+  const float* ap[C_::kALoads];
+#pragma unroll
+  for (int j = 0; j < C_::kALoads; ++j) {
+    a_slot(threadIdx.x + j * C_::kThreads, arow[j], akq[j]);
+    int gr = m0 + arow[j];
+    gr = gr < g.M ? gr : g.M - 1;
+    ap[j] = g.A + (int64_t)gr * g.lda;
+  }
+  const int brow_l = (threadIdx.x & 7) | ((threadIdx.x >> 4) << 3), bhalf = (threadIdx.x >> 3) & 1;
+  int brow = n0 + brow_l;
+  brow = brow < g.N ? brow : g.N - 1;
+  const unsigned short* bp = g.B3 + (int64_t)brow * g.ldb3 + bhalf * 8;
+  auto load = [&](int t, f32x4 (&ra)[C_::kALoads], u32x4 (&rb)[3]) {
+    const int tt = t < nk ? t : nk - 1;                                   // loads past the last step: clamped re-reads, never used
+#pragma unroll
+    for (int j = 0; j < C_::kALoads; ++j) {
+      const int gk = tt * BK3 + akq[j];
+      ra[j] = *reinterpret_cast<const f32x4*>(ap[j] + (gk < akmax ? gk : akmax));
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) rb[p] = *reinterpret_cast<const u32x4*>(bp + p * g.plane3 + (int64_t)tt * BK3);
+  };
+  auto store = [&](int buf, int t, const f32x4 (&ra)[C_::kALoads], const u32x4 (&rb)[3]) {
+#pragma unroll
+    for (int j = 0; j < C_::kALoads; ++j) {
+      f32x4 v = ra[j];
+      if (KTAIL) {                                                         // (K % 16 != 0 only: zero the floats of this float4 past K)
+        const int nvalid = g.K - (t * BK3 + akq[j]);
+        v.x = nvalid > 0 ? v.x : 0.f; v.y = nvalid > 1 ? v.y : 0.f; v.z = nvalid > 2 ? v.z : 0.f; v.w = nvalid > 3 ? v.w : 0.f;
+      }
+      unsigned int h0, m0_, l0, h1, m1, l1;
+      split_pair_bf16x3(v.x, v.y, h0, m0_, l0);
+      split_pair_bf16x3(v.z, v.w, h1, m1, l1);
+      const int off = arow[j] * P3 + akq[j];
+      *reinterpret_cast<u32x2*>(Ap(buf, 0) + off) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(Ap(buf, 1) + off) = u32x2{m0_, m1};
+      *reinterpret_cast<u32x2*>(Ap(buf, 2) + off) = u32x2{l0, l1};
+    }
+    const int boff = brow_l * P3 + bhalf * 8;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(Bp(buf, p) + boff) = rb[p];
+  };
+  // fragments of one step: 3 planes x TM (A) and 3 planes x TN (B), 16 bytes each
+  const int a_off = (wm * TM * 32 + li) * P3 + kh * 8, b_off = (wn * TN * 32 + li) * P3 + kh * 8;
+  auto read_frags = [&](int buf, bf16x8_t (&fa)[3][TM], bf16x8_t (&fb)[3][TN]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a) fa[p][a] = *reinterpret_cast<const bf16x8_t*>(Ap(buf, p) + a_off + a * 32 * P3);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) fb[p][b] = *reinterpret_cast<const bf16x8_t*>(Bp(buf, p) + b_off + b * 32 * P3);
+    }
+  };
+  // The six products, smallest first; consecutive MFMAs go to DIFFERENT accumulators (a dependent bf16 MFMA cannot issue back to back).
+  //   PA / PB: plane of A / B of product q
+  auto mfma_products = [&](const bf16x8_t (&fa)[3][TM], const bf16x8_t (&fb)[3][TN], int q0, int q1) {
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+    for (int q = q0; q < q1; ++q)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]][a], fb[PB[q]][b], acc[a][b], 0, 0, 0);
+  };
+
+  // THREE register stages: a step is only ~1500 cycles long here (the fp32 loop's is ~8000), so a tile is requested three steps before
+  // its MFMAs and two before it is split and written to LDS -- one step was less than the loaded L2 latency and every step began
+  // with a wait for memory.  Stages rotate with period 3, LDS buffers and fragment sets with period 2: the loop is unrolled by 6.
+  f32x4 ra[3][C_::kALoads];
+  u32x4 rb[3][3];
+  bf16x8_t fa[2][3][TM], fb[2][3][TN];
+  load(0, ra[0], rb[0]);
+  load(1, ra[1], rb[1]);
+  load(2, ra[2], rb[2]);
+  store(0, 0, ra[0], rb[0]);
+  __syncthreads();
+  read_frags(0, fa[0], fb[0]);
+  // step t: request tile t+3 (into the stage tile t held), stage tile t+1 into the other LDS buffer, MFMAs of tile t with the barrier
+  // and the fragment reads of tile t+1 before the last third of them
+  auto step = [&](int t, f32x4 (&ain)[C_::kALoads], u32x4 (&bin)[3], const f32x4 (&aout)[C_::kALoads], const u32x4 (&bout)[3],
+                  const bf16x8_t (&fa_)[3][TM], const bf16x8_t (&fb_)[3][TN], bf16x8_t (&fan)[3][TM], bf16x8_t (&fbn)[3][TN]) {
+    const int cur = t & 1;
+    load(t + 3, ain, bin);
+    store(cur ^ 1, t + 1, aout, bout);
+    mfma_products(fa_, fb_, 0, 4);
+    // Issue order of the 4 * TM * TN MFMAs before the barrier: the global loads first (one per MFMA), then the splitting arithmetic
+    // (5 VALU operations per MFMA: what a 32-cycle MFMA hides) with the LDS stores as they become ready.
+    constexpr int kPre = 4 * TM * TN;
+#pragma unroll
+    for (int i = 0; i < kPre; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i < C_::kALoads + 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      if (i >= kPre - (3 * C_::kALoads + 3)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    read_frags(cur ^ 1, fan, fbn);
+    mfma_products(fa_, fb_, 4, 6);
+#pragma unroll
+    for (int i = 0; i < 2 * TM * TN; ++i) {                                 // the fragment reads of the next step between the last MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, (3 * (TM + TN) + 2 * TM * TN - 1) / (2 * TM * TN), 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int t0 = 0; t0 < nk; t0 += 6) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (t0 + i < nk) step(t0 + i, ra[i % 3], rb[i % 3], ra[(i + 1) % 3], rb[(i + 1) % 3], fa[i % 2], fb[i % 2], fa[(i + 1) % 2], fb[(i + 1) % 2]);
+  }
+  __syncthreads();   // the epilogue reuses the operand buffers
+
+  float* stage = reinterpret_cast<float*>(smem_raw) + wave * (TM * 32 * (TN * 32 + 4));
+  const bool interior = m0 + C_::BM <= g.M && n0 + C_::BN <= (g.mode == SR_EPI_FWD ? g.N : (g.nact_bwd < g.N ? g.nact_bwd : g.N));
+  if (interior) {
+    if (g.mode == SR_EPI_FWD) {
+      switch (g.group) {
+        case 1: epilogue_interior_act<WM, WN, TM, TN, 1, SR_EPI_FWD>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
+        case 2: epilogue_interior_act<WM, WN, TM, TN, 2, SR_EPI_FWD>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
+        default: epilogue_interior_act<WM, WN, TM, TN, 4, SR_EPI_FWD>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
+      }
+    } else {
+      switch (g.group) {
+        case 1: epilogue_interior_act<WM, WN, TM, TN, 1, SR_EPI_BWD>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
+        case 2: epilogue_interior_act<WM, WN, TM, TN, 2, SR_EPI_BWD>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
+        default: epilogue_interior_act<WM, WN, TM, TN, 4, SR_EPI_BWD>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
+      }
+    }
+  } else {
+    switch (g.group) {
+      case 1: epilogue<WM, WN, TM, TN, 1>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
+      case 2: epilogue<WM, WN, TM, TN, 2>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
+      default: epilogue<WM, WN, TM, TN, 4>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
+    }
+  }
+}
+
+template <int WM, int WN, int TM, int TN, bool KTAIL>
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_bf16x3_kernel(sr_gemm_args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  gemm_nt_tile_bf16x3<WM, WN, TM, TN, KTAIL>(g, blockIdx.x, smem3);
+}
+
+// x -> three bf16 planes (weights, once per optimizer step); columns [cols, ld_dst) are written as zero
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ src, int64_t ld_src, int64_t rows, int cols,
+                                                            unsigned short* __restrict__ dst, int64_t ld_dst, int64_t plane) {
+  const int64_t total = rows * ld_dst;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / ld_dst;
+    const int c = (int)(i - r * ld_dst);
+    unsigned int h = 0, m = 0, l = 0;
+    if (c < cols) split_bf16x3(src[r * ld_src + c], h, m, l);
+    dst[i] = (unsigned short)h; dst[plane + i] = (unsigned short)m; dst[2 * plane + i] = (unsigned short)l;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Persistent layer chain: ONE launch runs up to SR_CHAIN_MAX_LAYERS consecutive layers of one or two independent MLPs
 // (e.g. layer l of the SDF and of the deformation network side by side) on a row count that lives in DEVICE memory.
 // The workgroups of a resident grid (2 per CU) walk the tiles of a layer with a stride of the grid size and meet at a
@@ -736,6 +989,25 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
     hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float),     \
                        (hipStream_t)stream, g);                                                                             \
   } while (0)
+  // opt-in split-bf16 path: B pre-split (B3), wide output, enough rows to fill the machine with 128 x 128 tiles
+  static const int bf16x3_min_rows = getenv("SR_BF16X3_MIN_ROWS") ? atoi(getenv("SR_BF16X3_MIN_ROWS")) : 8192;
+  if (g.B3 && ncols > 32 && g.M >= bf16x3_min_rows) {
+    if ((g.ldb3 & 15) || ((uintptr_t)g.B3 & 15) || (g.plane3 & 7) || g.ldb3 < ((g.K + 15) & ~15)) return SR_EINVAL;
+    using C3 = Cfg3<2, 2, 2, 2>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel<2, 2, 2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C3::kLdsBytes) != hipSuccess ||
+          hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel<2, 2, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C3::kLdsBytes) != hipSuccess)
+        return SR_ELAUNCH;
+      attr_set = true;
+    }
+    const int nwg = (int)(sr_cdiv(g.M, C3::BM) * sr_cdiv(ncols, C3::BN));
+    if (g.K % BK3)
+      hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<2, 2, 2, 2, true>), dim3(nwg), dim3(C3::kThreads), C3::kLdsBytes, (hipStream_t)stream, g);
+    else
+      hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<2, 2, 2, 2, false>), dim3(nwg), dim3(C3::kThreads), C3::kLdsBytes, (hipStream_t)stream, g);
+    return sr_launch_status();
+  }
   if (ncols <= 32) {
     // narrow outputs (the 3-wide deformer / render heads, the sdf-only last layer): 256x32 tiles for the template-sized batches,
     // 64x32 / 32x32 for the refiner's few thousand rows (6k rows are only 24 tiles of 256 rows on 256 CUs)
@@ -831,6 +1103,15 @@ int sr_mlp_chain(const sr_chain_args* a, void* stream) {
   if (grid <= 0) return SR_ELAUNCH;
   if (hipMemsetAsync(a->barrier, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return SR_ELAUNCH;
   hipLaunchKernelGGL(mlp_chain_kernel, dim3(grid), dim3(ChainCfg::kThreads), ChainCfg::kLdsFloats * sizeof(float), (hipStream_t)stream, *a);
+  return sr_launch_status();
+}
+
+int sr_split_bf16x3(const float* src, int64_t ld_src, int64_t rows, int32_t cols, uint16_t* dst, int64_t ld_dst, int64_t plane_stride, void* stream) {
+  if (rows < 0 || cols <= 0 || ld_src < cols || ld_dst < cols || (ld_dst & 15) || plane_stride < rows * ld_dst) return SR_EINVAL;
+  if (rows == 0) return SR_OK;
+  if (!src || !dst) return SR_EINVAL;
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3(sr_stream_grid(rows * ld_dst, 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src, rows, cols, dst, ld_dst,
+                     plane_stride);
   return sr_launch_status();
 }
 
