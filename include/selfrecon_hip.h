@@ -350,7 +350,9 @@ int sr_unpack_grads(const sr_unpack_table* host_table, void* stream);
  * inv_sqrt_bias2 = 1 / sqrt(1 - beta2^step) (host-side scalars of the tensor's step count). */
 #define SR_ADAM_MAX_TENSORS 64
 typedef struct { float* p; const float* g; float* m; float* v; int64_t numel; float lr, bias1, inv_sqrt_bias2, pad_; } sr_adam_tensor;
-typedef struct { int32_t ntensors; float beta1, beta2, eps; sr_adam_tensor tensor[SR_ADAM_MAX_TENSORS]; } sr_adam_table;
+typedef struct { int32_t ntensors; float beta1, beta2, eps;
+                 float one_minus_beta1, one_minus_beta2;   /* formed in double on the host: 1 - 0.999f is off by 1.3e-5 relative in float */
+                 int32_t pad_[2]; sr_adam_tensor tensor[SR_ADAM_MAX_TENSORS]; } sr_adam_table;
 int sr_adam_step(const sr_adam_table* host_table, void* stream);
 
 /* ---------------------------------------------------------------- interp2x_boundary3d (K10/K11)

@@ -95,6 +95,7 @@ class SrAdamTensor(ctypes.Structure):
 
 class SrAdamTable(ctypes.Structure):
     _fields_ = [("ntensors", ctypes.c_int32), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
+                ("one_minus_beta1", ctypes.c_float), ("one_minus_beta2", ctypes.c_float), ("pad_", ctypes.c_int32 * 2),
                 ("tensor", SrAdamTensor * SR_ADAM_MAX_TENSORS)]
 
 

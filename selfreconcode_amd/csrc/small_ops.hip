@@ -162,13 +162,13 @@ __global__ __launch_bounds__(256) void rows_pad_kernel(const float* __restrict__
 // torch's multi-tensor implementation issues ~10 launches with 40 us of host time between them at the end of every iteration.
 __global__ __launch_bounds__(256) void adam_step_kernel(sr_adam_table t) {
   const sr_adam_tensor T = t.tensor[blockIdx.y];
-  const float b1 = t.beta1, b2 = t.beta2, eps = t.eps;
+  const float b2 = t.beta2, eps = t.eps, w1 = t.one_minus_beta1, w2 = t.one_minus_beta2;
   const float step_size = T.lr / T.bias1, inv_sqrt_bias2 = T.inv_sqrt_bias2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T.numel; i += (int64_t)gridDim.x * blockDim.x) {
     const float g = T.g[i];
     float m = T.m[i], v = T.v[i];
-    m = m + (g - m) * (1.0f - b1);
-    v = v * b2 + (1.0f - b2) * g * g;
+    m = m + (g - m) * w1;
+    v = v * b2 + w2 * g * g;
     T.m[i] = m; T.v[i] = v;
     const float denom = sqrtf(v) * inv_sqrt_bias2 + eps;
     T.p[i] = T.p[i] - step_size * (m / denom);

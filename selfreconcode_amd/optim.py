@@ -47,6 +47,7 @@ class FusedAdam(torch.optim.Optimizer):
                 chunk = todo[i:i + _lib.SR_ADAM_MAX_TENSORS]
                 t = _lib.SrAdamTable()
                 t.ntensors, t.beta1, t.beta2, t.eps = len(chunk), b1, b2, group['eps']
+                t.one_minus_beta1, t.one_minus_beta2 = 1.0 - b1, 1.0 - b2             # (double arithmetic, then rounded once)
                 for j, (p, g, st) in enumerate(chunk):
                     k = float(st['step'])
                     T = t.tensor[j]
