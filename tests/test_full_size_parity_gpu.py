@@ -197,6 +197,23 @@ def _collect_step(net, ds, V0, loss, nets):
     return out
 
 
+def _group_noise(noise):
+    """The noise floor of a quantity is estimated from ONE perturbed run, and the event behind it -- which (point, pixel) pairs flip --
+    is a different draw in every run.  Quantities that share the path behind those events share the estimate: the largest one of
+    their group (parameters of one network; per-frame tensors and camera tensors; the template step; everything else on its own)."""
+    def group(k):
+        if k.startswith(("sdf.", "tr.", "rn.")):
+            return k.split(".")[0]
+        if k in ("poses", "trans", "dcond", "focal", "princ", "T"):
+            return "frames+camera"
+        return k
+    worst = {}
+    for k, v in noise.items():
+        gk = group(k)
+        worst[gk] = (max(worst.get(gk, (0., 0.))[0], v[0]), max(worst.get(gk, (0., 0.))[1], v[1]))
+    return {k: worst[group(k)] for k in noise}
+
+
 def _noise(a, b):
     a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
     if a.shape != b.shape or b.numel() == 0:
@@ -285,7 +302,7 @@ def test_full_size_iteration_vs_the_references_own_run(golden, stage):
     res2 = _collect_step(net2, ds2, V0p, loss2, nets2)
     for name in corr2:
         res2["sdf." + name] = res2["sdf." + name] + corr2[name]
-    noise = {k: _noise(res2[k], res[k]) for k in res}
+    noise = _group_noise({k: _noise(res2[k], res[k]) for k in res})
 
     def tol(name, base_frac, base_rl2):
         return max(base_frac, 4 * noise[name][0]), max(base_rl2, 4 * noise[name][1])
@@ -418,7 +435,7 @@ def test_full_size_bench_scene_iteration_vs_cpu_oracle():
     res2 = _collect_step(net2, ds2, V0p.cpu(), loss2, (net2.sdf, net2.deformer.defs[0], net2.netRender))
     for name in corr2:
         res2["sdf." + name] = res2["sdf." + name] + corr2[name]
-    noise = {k: _noise(res2[k], res[k]) for k in res}
+    noise = _group_noise({k: _noise(res2[k], res[k]) for k in res})
     tol = lambda name, bf_, bl: (max(bf_, 4 * noise[name][0]), max(bl, 4 * noise[name][1]))
     rep = Report()
     rep.cmp(dbg['seeds'], info['p0'], 1e-5, 1e-5, "seeds")
