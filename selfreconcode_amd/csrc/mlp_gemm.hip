@@ -414,13 +414,10 @@ __device__ __forceinline__ void gemm_nt_tile(const sr_gemm_args& g, int wg, floa
 }
 
 template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_kernel(sr_gemm_args g, int dephase) {
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_kernel(sr_gemm_args g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // Tuning switch (SR_NT_DEPHASE = sleeps of 8128 cycles): the two workgroups that share a CU start together and, running the same
-  // code at the same speed, stay in phase -- their prologues and epilogues (no MFMA issue) coincide.  Delaying the second resident of
-  // the first round (workgroups 256..511 land on the CUs that already hold 0..255) by part of a tile would interleave them.
-  if (dephase > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
-    for (int i = 0; i < dephase; ++i) __builtin_amdgcn_s_sleep(127);
+  // (Tried in round 3: delaying the second workgroup of every CU by 0.1 - 0.6 of a tile at the start of a launch, so that the two
+  // co-resident workgroups do not run their prologues / epilogues in phase -- no effect, 119.0 +- 0.4 TFLOP/s at every delay.)
   gemm_nt_tile<WM, WN, TM, TN>(g, blockIdx.x, smem);
 }
 
@@ -983,7 +980,6 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
   sr_gemm_args g = *a;
   if (g.mode != SR_EPI_FWD) g.naux_fwd = 0;
   // Tile choice by a cost model, see below.
-  static const int dephase = getenv("SR_NT_DEPHASE") ? atoi(getenv("SR_NT_DEPHASE")) : 0;
   auto cost = [&](int bm, int bn, double eff) {
     const int64_t wgs = sr_cdiv(g.M, bm) * sr_cdiv(ncols, bn);
     return (double)sr_cdiv(wgs, 256) * bm * bn / eff;
@@ -993,7 +989,7 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
     using C_ = Cfg<WM, WN, TM, TN>;                                                                                         \
     const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));                                                   \
     hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float),     \
-                       (hipStream_t)stream, g, nwg > 512 ? dephase : 0);                                                    \
+                       (hipStream_t)stream, g);                                                                             \
   } while (0)
   // opt-in split-bf16 path: B pre-split (B3), wide output, enough rows to fill the machine with 128 x 128 tiles
   static const int bf16x3_min_rows = getenv("SR_BF16X3_MIN_ROWS") ? atoi(getenv("SR_BF16X3_MIN_ROWS")) : 8192;

@@ -281,30 +281,45 @@ def test_full_size_iteration_vs_the_references_own_run(golden, stage):
     for name in corr:
         res["sdf." + name] = res["sdf." + name] + corr[name]
 
-    # (c) the noise floor: the same iteration with the template perturbed by one ulp; refiner output of the nominal run, matched by pixel
-    net2, ds2, datas2, _, nets2 = _golden_scene(g, stage)
-    V0p = V0 * (1.0 + 1e-7 * fx.det_tensor(tuple(V0.shape), 4242, 1.0))
-    net2.TmpVs = V0p.to(DEV).clone().requires_grad_(True)
-    net2.TmpOptimizer = torch.optim.SGD([net2.TmpVs], lr=0.05, momentum=0.9)
-    mlp_engine.set_deferred_param_grads(True)
-    state = {}
-    try:
-        with keyed_refiner(state, int(g["HW"][0]), int(g["HW"][1])):
-            dbg2 = {}
-            state.update(dbg=dbg2, ref=(dbg['batch_inds'], dbg['row_inds'], dbg['col_inds'], g["sel_p1"], ref_ok))
-            loss2 = net2(datas2, SP, RATIO, fids, rand=rand, debug=dbg2)
-            loss2.backward()
-            net2.propagateTmpPsGrad(fids, RATIO)
-    finally:
-        mlp_engine.set_deferred_param_grads(False)
-    assert state['matched'][0] >= 0.995 * state['matched'][2], state['matched']
-    corr2, _ = l1_sign_correction(net2, g["f_moved_x1024"].float() / 1024., float(g["pc_weight"]), RATIO)
-    res2 = _collect_step(net2, ds2, V0p, loss2, nets2)
-    for name in corr2:
-        res2["sdf." + name] = res2["sdf." + name] + corr2[name]
-    noise = _group_noise({k: _noise(res2[k], res[k]) for k in res})
+    # (c) the noise floor: the same iteration with the template perturbed by one ulp (three different perturbations: which decisions
+    #     flip is a draw); refiner output of the nominal run, matched by pixel
+    noise = {}
+    for twin in range(3):
+        net2, ds2, datas2, _, nets2 = _golden_scene(g, stage)
+        V0p = V0 * (1.0 + 1e-7 * fx.det_tensor(tuple(V0.shape), 4242 + twin, 1.0))
+        net2.TmpVs = V0p.to(DEV).clone().requires_grad_(True)
+        net2.TmpOptimizer = torch.optim.SGD([net2.TmpVs], lr=0.05, momentum=0.9)
+        mlp_engine.set_deferred_param_grads(True)
+        state = {}
+        try:
+            with keyed_refiner(state, int(g["HW"][0]), int(g["HW"][1])):
+                dbg2 = {}
+                state.update(dbg=dbg2, ref=(dbg['batch_inds'], dbg['row_inds'], dbg['col_inds'], g["sel_p1"], ref_ok))
+                loss2 = net2(datas2, SP, RATIO, fids, rand=rand, debug=dbg2)
+                loss2.backward()
+                net2.propagateTmpPsGrad(fids, RATIO)
+        finally:
+            mlp_engine.set_deferred_param_grads(False)
+        assert state['matched'][0] >= 0.995 * state['matched'][2], state['matched']
+        corr2, _ = l1_sign_correction(net2, g["f_moved_x1024"].float() / 1024., float(g["pc_weight"]), RATIO)
+        res2 = _collect_step(net2, ds2, V0p, loss2, nets2)
+        for name in corr2:
+            res2["sdf." + name] = res2["sdf." + name] + corr2[name]
+        for k in res:
+            n = _noise(res2[k], res[k])
+            noise[k] = (max(noise.get(k, (0., 0.))[0], n[0]), max(noise.get(k, (0., 0.))[1], n[1]))
+        del net2, ds2, datas2, nets2, res2
+    noise = _group_noise(noise)
+
+    # In the default mode the layer GEMMs are exact-fp32 MFMA chains and reproduce the reference's float32 numbers so closely (SDF
+    # gradients to ~2e-5) that only the decision noise above matters.  With SR_GEMM=bf16x3 every large GEMM rounds differently at the
+    # 1e-7 level (its error against float64 is BELOW the fp32 kernel's, tests/test_mlp_gpu.py), and the bias gradients -- column sums of
+    # ~10^5 cotangent rows that cancel to a thousandth of their terms -- move by up to 6e-3: the bound for gradients is 8e-3 there.
+    grad_base = 4e-3 if mlp_engine.GEMM_MODE == "f32" else 8e-3
 
     def tol(name, base_frac, base_rl2):
+        if base_frac == 4e-3:
+            base_frac = base_rl2 = grad_base
         return max(base_frac, 4 * noise[name][0]), max(base_rl2, 4 * noise[name][1])
     for k in ('mask_loss', 'defconst_loss', 'grad_loss', 'def_loss', 'dct_loss', 'color_loss', 'normal_loss', 'offset_loss'):
         rep.cmp(res["L_" + k], g["L_" + k], *tol("L_" + k, 3e-4, 3e-4), k)
@@ -319,7 +334,7 @@ def test_full_size_iteration_vs_the_references_own_run(golden, stage):
             key = f"{tag}.{name}"
             t = tol(key, 4e-3, 4e-3)
             rep.digest(res[key], g["d_" + key], 100 * k, t[1], key + " (whole)")
-            rep.cmp(slice_of(res[key]), g["s_" + key], t[0], max(6e-3, t[1]), key + " (slice)")
+            rep.cmp(slice_of(res[key]), g["s_" + key], t[0], max(1.5 * grad_base, t[1]), key + " (slice)")
     assert ds.conds[1].grad is None or float(ds.conds[1].grad.abs().max()) == 0.0
     loud = {k: (round(v[0], 5), round(v[1], 5)) for k, v in noise.items() if max(v) > 1e-3}
     print("noise floor (product vs itself with a 1-ulp template perturbation), entries above 1e-3:", loud)
