@@ -7,14 +7,17 @@ for r in csv.DictReader(open(f)):
     rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
 rows.sort()
 if len(sys.argv) > 3:
-    # window of whole iterations [A, B) counted in Adam steps (multi_tensor_apply bursts of >= 4 kernels): e.g. the clean pass of bench.py
+    # window of whole iterations [A, B) counted in Adam steps: the one-launch FusedAdam kernel (adam_step_kernel) ends an iteration; with
+    # torch.optim.Adam (bench.py --torch-adam) a burst of >= 4 multi_tensor_apply kernels does
     A, B = int(sys.argv[2]), int(sys.argv[3])
-    bursts = []
-    for s, e, n in rows:
-        if 'multi_tensor_apply' in n:
-            if not bursts or s - bursts[-1][-1] > 2_000_000: bursts.append([s])
-            else: bursts[-1].append(s)
-    ends = [b[-1] for b in bursts if len(b) >= 4]
+    ends = [s for s, e, n in rows if 'adam_step_kernel' in n]        # (one launch per step for <= 64 parameter tensors)
+    if not ends:
+        bursts = []
+        for s, e, n in rows:
+            if 'multi_tensor_apply' in n:
+                if not bursts or s - bursts[-1][-1] > 2_000_000: bursts.append([s])
+                else: bursts[-1].append(s)
+        ends = [b[-1] for b in bursts if len(b) >= 4]
     t0, t1 = ends[A - 1], ends[B - 1]
     rows = [r for r in rows if t0 < r[0] <= t1 + 100_000]
     print(f'window: iterations {A}..{B - 1} of {len(ends)} ({(t1 - t0) / 1e6 / (B - A):.2f} ms / iteration under tracing)')

@@ -18,6 +18,9 @@ for s in opt:
     if not bursts or s - bursts[-1][-1] > 2_000_000: bursts.append([s])
     else: bursts[-1].append(s)
 ends = [b[-1] for b in bursts if len(b) >= 4]          # Adam (several multi-tensor launches); the template SGD step is a 1-2 kernel burst
+fused = [s for s, e, n, q in rows if 'adam_step_kernel' in n]          # the one-launch FusedAdam ends an iteration when it is in use
+if fused:
+    ends = fused
 assert len(ends) > k + 1, len(ends)
 t0, t1 = ends[-k - 2], ends[-k - 1]
 it = [r for r in rows if t0 < r[0] <= t1 + 200_000]
