@@ -355,6 +355,18 @@ typedef struct { int32_t ntensors; float beta1, beta2, eps;
                  int32_t pad_[2]; sr_adam_tensor tensor[SR_ADAM_MAX_TENSORS]; } sr_adam_table;
 int sr_adam_step(const sr_adam_table* host_table, void* stream);
 
+/* Cross-stream ordering through device memory (no reference counterpart: the reference runs one stream).
+ * hipStreamWaitEvent on this runtime makes the waiting stream wait for EVERYTHING the recording stream holds when the wait is
+ * processed, not for the recorded point (tools/stream_latency2.py: a side stream that waits for an event recorded in the middle of
+ * a busy main stream starts after the main stream has drained).  _set stores `value` to *flag when the stream reaches it; _wait
+ * holds its stream (one sleeping wave) until *flag - value >= 0 in wrapping 32-bit arithmetic, or until timeout_ms has passed, in
+ * which case *timed_out (optional) is incremented and the stream proceeds -- the caller must treat that as an error. */
+/* Diagnostics: writes the device's constant 100 MHz counter to *out when the stream reaches this point (timestamps that are
+ * comparable across streams, which the runtime's event timestamps are not: tools/host_profile.py). */
+int sr_stream_stamp(uint64_t* out, void* stream);
+int sr_stream_flag_set(uint32_t* flag, uint32_t value, void* stream);
+int sr_stream_flag_wait(const uint32_t* flag, uint32_t value, uint32_t* timed_out, int32_t timeout_ms, void* stream);
+
 /* ---------------------------------------------------------------- interp2x_boundary3d (K10/K11)
  * Replaces MCAcc/cuda/interp2x_boundary3d.cpp:forward/backward -> interp2x_boundary3d_kernel.cu:11-151, 155-239
  * (compiled but never enabled in the reference: every Seg3dLossless is built with use_cuda_impl=False).

@@ -178,6 +178,9 @@ SIGNATURES = {
     "sr_rows_frame_sum_workspace_floats": [_i64, ctypes.c_int32, ctypes.c_int32],
     "sr_rows_frame_sum": [_vp, _i64, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _vp, _vp],
     "sr_adam_step": [_vp, _vp],
+    "sr_stream_stamp": [_vp, _vp],
+    "sr_stream_flag_set": [_vp, ctypes.c_uint32, _vp],
+    "sr_stream_flag_wait": [_vp, ctypes.c_uint32, _vp, ctypes.c_int32, _vp],
     "sr_pack_weights": [_vp, _vp],
     "sr_unpack_grads": [_vp, _vp],
     "sr_svd3x3": [_vp, _i64, _vp, _vp, _vp, _vp],

@@ -160,6 +160,21 @@ __global__ __launch_bounds__(256) void rows_pad_kernel(const float* __restrict__
 // Adam step of up to SR_ADAM_MAX_TENSORS parameter tensors in ONE launch (torch.optim.Adam without weight decay / amsgrad, the
 // optimizer of train.py:139: m <- m + (1 - b1)(g - m);  v <- b2 v + (1 - b2) g g;  p <- p - lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)).
 // torch's multi-tensor implementation issues ~10 launches with 40 us of host time between them at the end of every iteration.
+// ---- cross-stream ordering through device memory (see the header: sr_stream_flag_set / _wait) ----
+__global__ void stream_stamp_kernel(unsigned long long* out) {
+  if (threadIdx.x == 0) *out = wall_clock64();
+}
+__global__ void stream_flag_set_kernel(unsigned* flag, unsigned value) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void stream_flag_wait_kernel(const unsigned* flag, unsigned value, unsigned* timed_out, unsigned long long max_ticks) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long t0 = wall_clock64();                       // 100 MHz constant counter
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
+    __builtin_amdgcn_s_sleep(64);
+    if (wall_clock64() - t0 > max_ticks) { if (timed_out) atomicAdd(timed_out, 1u); break; }   // never hang the queue: the caller checks the counter
+  }
+}
 __global__ __launch_bounds__(256) void adam_step_kernel(sr_adam_table t) {
   const sr_adam_tensor T = t.tensor[blockIdx.y];
   const float b2 = t.beta2, eps = t.eps, w1 = t.one_minus_beta1, w2 = t.one_minus_beta2;
@@ -238,6 +253,21 @@ int sr_rows_frame_sum(const float* X, int64_t ldx, int64_t P, int32_t E, const i
   hipLaunchKernelGGL(rows_frame_sum_kernel, dim3((unsigned)sr_cdiv(E, kFsCols), slices), dim3(kFsCols * kFsGroups), sizeof(float) * kFsGroups * n * kFsCols,
                      (hipStream_t)stream, X, ldx, P, E, index, n, rows_per_slice, partial);
   hipLaunchKernelGGL(rows_frame_sum_finish, dim3(sr_stream_grid((int64_t)n * E, 256)), dim3(256), 0, (hipStream_t)stream, partial, slices, (int64_t)n * E, out);
+  return sr_launch_status();
+}
+int sr_stream_stamp(uint64_t* out, void* stream) {
+  if (!out) return SR_EINVAL;
+  hipLaunchKernelGGL(stream_stamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out);
+  return sr_launch_status();
+}
+int sr_stream_flag_set(uint32_t* flag, uint32_t value, void* stream) {
+  if (!flag) return SR_EINVAL;
+  hipLaunchKernelGGL(stream_flag_set_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value);
+  return sr_launch_status();
+}
+int sr_stream_flag_wait(const uint32_t* flag, uint32_t value, uint32_t* timed_out, int32_t timeout_ms, void* stream) {
+  if (!flag || timeout_ms <= 0) return SR_EINVAL;
+  hipLaunchKernelGGL(stream_flag_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, timed_out, (unsigned long long)timeout_ms * 100000ull);
   return sr_launch_status();
 }
 int sr_adam_step(const sr_adam_table* t, void* stream) {

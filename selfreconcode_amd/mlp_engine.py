@@ -681,9 +681,17 @@ def pack_linear(lin):
 
 
 def transposed_of(W, K):
+    """W^T for the backward-data GEMM: the packed transpose, or -- for a leading block of a packed weight (the first K input columns
+    of a first layer whose per-frame code was hoisted out, the first row of the sdf-only last layer) -- the matching block of it
+    (same row pitch; the GEMM masks the contraction tail, so the columns past N inside the 16-byte pad are never used)."""
     WT = _WT_BY_PTR.get(W.data_ptr())
-    if WT is not None and WT.shape == (K, pad4(W.shape[0])):
-        return WT
+    if WT is not None:
+        if WT.shape == (K, pad4(W.shape[0])):
+            return WT
+        e = _ENTRY_BY_PTR.get(W.data_ptr())
+        if (e is not None and e["WT"] is WT and W.stride(0) == e["W"].stride(0) and W.shape[0] <= e["W"].shape[0]
+                and K <= WT.shape[0] and pad4(W.shape[0]) <= WT.shape[1]):
+            return WT[:K, :pad4(W.shape[0])]
     return transpose_padded(W, K)
 
 

@@ -14,6 +14,16 @@ from ..utils.utils import resolve_band_weights
 HOIST_FRAME_CODE = os.environ.get('SR_HOIST_FRAME_CODE', '1') != '0'     # frame-major batches: per-frame code product out of the deformer's first-layer GEMM (MLPTranslator.hoisted_first_layer)
 
 
+_EYE3 = {}
+
+
+def _eye3(device):
+    e = _EYE3.get(device)
+    if e is None:
+        e = _EYE3[device] = torch.eye(3, device=device)
+    return e
+
+
 class CompositeDeformer(nn.Module):
     def __init__(self, deformers):
         super().__init__()
@@ -482,7 +492,7 @@ class TranslatorValueJacobian(torch.autograd.Function):
             acts = me.forward(spec, A0, Ws, bs, 4)
         out = acts[-1].view(P, 4, -1)[:, :, :3]
         d = flat + out[:, 0]
-        J = out[:, 1:4].transpose(1, 2) + torch.eye(3, device=flat.device)         # J[p, r, c] = delta + d off_r / d x_c
+        J = out[:, 1:4].transpose(1, 2) + _eye3(flat.device)         # J[p, r, c] = delta + d off_r / d x_c
         ctx.tr, ctx.wt, ctx.segment, ctx.n_extra, ctx.xshape, ctx.spec, ctx.E = tr, wt, segment, 0 if cd is None else cd.shape[0], x.shape, spec, E
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(flat, index, A0, *wb, *acts[:-1])

@@ -16,12 +16,14 @@ Deliberate differences (all documented in DESIGN.md):
 """
 import os
 
+import time
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import dist as srdist
+from .. import hostsync
 from .. import mlp_engine
 from .. import step_ops
 from ..ext import MCGpu
@@ -32,6 +34,7 @@ from ..utils.FindSurfacePs import FindSurfacePs, OptimizeSurfacePs
 from .CameraMine import RectifiedPerspectiveCameras
 
 
+SPLIT_SAMPLE_TERMS = os.environ.get('SR_SPLIT_SAMPLE_TERMS', '0') != '0'    # see forward(): refiner-independent part of the sampled terms first
 _SIDE_STREAMS = {}
 
 
@@ -61,6 +64,7 @@ class OptimNetwork(nn.Module):
         self.TmpVs = None
         self.Tmpfs = None
         self.forward_time = 0
+        self.host_marks = None        # diagnostics (tools/host_profile.py): a list that receives (label, host time, event on the main stream)
         self.remesh_intersect = 30
         self.remesh_time = 0.
         self.point_radius = 0.006             # train.coarse.point_render.radius (config.conf:30)
@@ -251,6 +255,14 @@ class OptimNetwork(nn.Module):
         return out
 
     # ------------------------------------------------------------------ rasterisation stand-ins
+    def _mark(self, label):
+        """Diagnostics: host time + a device-clock stamp on the CURRENT stream (sr_stream_stamp; slot index into self.mark_stamps)."""
+        if self.host_marks is not None:
+            from .. import _lib
+            i = len(self.host_marks)
+            _lib.call('sr_stream_stamp', self.mark_stamps.data_ptr() + 8 * i, torch.cuda.current_stream().cuda_stream)
+            self.host_marks.append((label, time.perf_counter(), i))
+
     def _side_stream(self, device, which=0):
         # One set of streams per PROCESS and device, not per network object: the runtime multiplexes streams onto a few hardware
         # queues, and a second network's fresh streams can land on the queue of the weight-gradient stream (mlp_engine) -- its
@@ -335,7 +347,9 @@ class OptimNetwork(nn.Module):
         TmpVnum = self.TmpVs.shape[0]
         poses, trans, d_cond, rendcond = self.dataset.get_grad_parameters(frame_ids, device)
         defconds = [d_cond, [poses, trans]]
+        self._mark('start')
         defTmpVs = self.deformer(self.TmpVs[None, :, :].expand(N, -1, 3), defconds, ratio=ratio)
+        self._mark('template deformed')
         self.info['pc_loss'] = {}
 
         # Two streams.  The template branch (silhouette, mask loss, its backward, the template SGD step, |f(TmpVs)|) is a few
@@ -356,6 +370,7 @@ class OptimNetwork(nn.Module):
         radius = int(np.round(self.point_radius / 2. * float(min(H, W)) / 1.2))
         mgtMs = F.max_pool2d(gtMs, kernel_size=2 * radius + 1, stride=1, padding=radius) if radius > 0 else gtMs
         total_loss = self.computeTmpPcLoss(defTmpVs, defconds, masks, mgtMs, ratio)
+        self._mark('template branch issued')
 
         with torch.cuda.stream(side):
             side.wait_event(fork)
@@ -363,19 +378,24 @@ class OptimNetwork(nn.Module):
                 if 'frags' in datas:
                     batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(seedVs, self.Tmpfs, datas['frags'])
                 elif self.seed_mode == "mesh":            # in-repo hard mesh rasteriser -> FindSurfacePs, as the reference does with pytorch3d
+                    self._mark('sel: entered')
                     xy, z = cameras.project_ndc(defTmpVs.detach())
+                    self._mark('sel: projected')
                     frags = rasterize_meshes(xy, z, self.Tmpfs, H, W)
+                    self._mark('sel: rasterised')
                     batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(seedVs, self.Tmpfs, frags)
+                    self._mark('sel: seeds found')
                 else:
                     batch_inds, row_inds, col_inds, initTmpPs = self._seed_rays(defTmpVs.detach(), cameras, H, W, seedVs)
             # boolean masks are turned into index lists ONCE (each `x[mask]` is its own nonzero + host sync)
-            sel = (gtMs[batch_inds, row_inds, col_inds] > 0.).nonzero(as_tuple=False).view(-1)
+            sel = hostsync.nonzero(gtMs[batch_inds, row_inds, col_inds] > 0.).view(-1)
             batch_inds, row_inds, col_inds, initTmpPs = batch_inds[sel], row_inds[sel], col_inds[sel], initTmpPs[sel]
+            self._mark('sel: inside the mask')
             pnum = batch_inds.shape[0]
             sample_pix = self.conf.get_int('sample_pix_num') if 'sample_pix_num' in self.conf else sample_pix
             if pnum > sample_pix * N:
                 u = rand['ray_select'][:pnum] if 'ray_select' in rand else torch.rand(pnum, device=device)
-                sel = (u < float(sample_pix * N) / float(pnum)).nonzero(as_tuple=False).view(-1)
+                sel = hostsync.nonzero(u < float(sample_pix * N) / float(pnum)).view(-1)
                 batch_inds, row_inds, col_inds, initTmpPs = batch_inds[sel], row_inds[sel], col_inds[sel], initTmpPs[sel]
                 pnum = batch_inds.shape[0]
             pixels = torch.stack([col_inds, row_inds, torch.ones_like(col_inds)], dim=-1).float()
@@ -389,6 +409,7 @@ class OptimNetwork(nn.Module):
         # the default: its short layer launches fill the gaps and tails of the template branch's large kernels, ~2 ms / iteration),
         # or follows it on the main stream ("main": what bench.py's instrumented pass uses, because with two streams of GEMMs no
         # per-kernel duration -- events or rocprof -- is a kernel's own any more).
+        self._mark('rays selected')
         on_side = getattr(self, 'refiner_stream', 'side') == 'side'
         rstream = side if on_side else main
         if not on_side:
@@ -413,6 +434,7 @@ class OptimNetwork(nn.Module):
                 r1.record(rstream); rev.append((r0, r1))
             refined = torch.cuda.Event()
             refined.record(rstream)
+        self._mark('refiner issued')
         aux = self._side_stream(device, 1)
         with torch.cuda.stream(aux), torch.no_grad():
             # vertex subsets of the eikonal / def-regu samples: the Bernoulli masks do not depend on the vertex positions, so their
@@ -421,31 +443,68 @@ class OptimNetwork(nn.Module):
             # as in the reference
             aux.wait_event(fork)
             vsel = rand['vert_select'][:TmpVnum] if 'vert_select' in rand else torch.rand(TmpVnum, device=device)
-            eik_idx = (vsel < 4096. / float(TmpVnum)).nonzero(as_tuple=False).view(-1)
+            eik_idx = hostsync.nonzero(vsel < 4096. / float(TmpVnum)).view(-1)
             use_regu = 'def_regu' in self.conf and self.conf.get_float('def_regu.weight') > 0.
             regu_idx = None
             if use_regu:
                 vsel2 = rand['vert_select2'][:TmpVnum] if 'vert_select2' in rand else torch.rand(TmpVnum, device=device)
-                regu_idx = (vsel2 < 4096. / float(TmpVnum)).nonzero(as_tuple=False).view(-1)
+                regu_idx = hostsync.nonzero(vsel2 < 4096. / float(TmpVnum)).view(-1)
+        # The eikonal and deformation-regulariser samples are [refined ray points ; a random subset of the template vertices] (+ uniform
+        # samples): the vertex / uniform part does not depend on the refiner, which -- 200 dependent launches of a few thousand rows each,
+        # under the template branch's large kernels -- finishes ~2.5 ms AFTER the main stream has drained the template branch
+        # (tools/host_profile.py).  So each term is evaluated as two batches: the refiner-independent one is queued before the main
+        # stream waits for the refiner, the ray one after it; the means are recombined with their counts (SPLIT_SAMPLE_TERMS = False:
+        # one batch each, as the reference writes it).
         main.wait_stream(aux)
+        for t in (eik_idx, regu_idx):
+            if t is not None:
+                t.record_stream(main)
+        poses, trans, d_cond, rendcond = self.dataset.get_grad_parameters(frame_ids, device)     # (the inner backward freed the first set's graph)
+        defconds = [d_cond, [poses, trans]]
+        nr = batch_inds.shape[0]
+        split = SPLIT_SAMPLE_TERMS and nr > 0 and eik_idx.numel() > 0
+        n_base = nr + eik_idx.shape[0]
+        n_glob = n_base // 6
+        nl = rand['eik_local'][:n_base] if 'eik_local' in rand else torch.randn(n_base, 3, device=device)
+        ng = rand['eik_global'][:n_glob] if 'eik_global' in rand else torch.rand(n_glob, 3, device=device)
+        use_regu_split = split and use_regu and regu_idx.numel() > 0
+        if use_regu:
+            n_regu = nr + regu_idx.shape[0]
+            nl2 = rand['regu_local'][:n_regu] if 'regu_local' in rand else torch.randn(n_regu, 3, device=device)
+        if split:
+            eikA_pts = torch.cat([self.TmpVs.detach()[eik_idx] + nl[nr:] * 0.01, ng * (1.8 * 2) - 1.8], dim=0)
+            eikA = self._eikonal_mean(eikA_pts, ratio)
+        if use_regu_split:
+            vA = self.TmpVs.detach()[regu_idx]
+            defA = self._def_regu_mean(torch.cat([vA, vA + nl2[nr:] * 0.01], dim=0), d_cond, N, ratio)
+        self._mark('vertex-part samples issued')
+
         main.wait_stream(side)
         mlp_engine.PROFILE.overlap = False
-        for t in (batch_inds, row_inds, col_inds, initTmpPs, rays, eik_idx, regu_idx, pixels, check):
+        for t in (batch_inds, row_inds, col_inds, initTmpPs, rays, pixels, check):
             if t is not None:
                 t.record_stream(main)
 
-        poses, trans, d_cond, rendcond = self.dataset.get_grad_parameters(frame_ids, device)
-        defconds = [d_cond, [poses, trans]]
         self.info['rayInfo'] = (check.numel(), check.sum())
         self.TmpPs = None
         if debug is not None:
             debug.update(initTmpPs=initTmpPs, check=check, rays=rays)
 
-        # --- eikonal (network.py:543-549)
-        base = torch.cat([initTmpPs, self.TmpVs.detach()[eik_idx]], dim=0)
-        grad_loss = self.loss_eikonal(base, ratio, rand.get('eik_local'), rand.get('eik_global'))
+        # --- eikonal (network.py:543-549; sample_points utils.py:74-84)
+        if split:
+            eikB_pts = initTmpPs + nl[:nr] * 0.01
+            eikB = self._eikonal_mean(eikB_pts, ratio)
+            nA, nB = eikA_pts.shape[0], eikB_pts.shape[0]
+            grad_loss = eikA * (float(nA) / float(nA + nB)) + eikB * (float(nB) / float(nA + nB))
+            self._eik_pts = torch.cat([eikB_pts.detach(), eikA_pts.detach()], dim=0)      # the reference's order: rays, vertices, uniform
+        else:
+            base = torch.cat([initTmpPs, self.TmpVs.detach()[eik_idx]], dim=0)
+            pts = torch.cat([base + nl * 0.01, ng * (1.8 * 2) - 1.8], dim=0)
+            self._eik_pts = pts.detach()
+            grad_loss = self._eikonal_mean(pts, ratio)
         self.info['grad_loss'] = grad_loss.detach()
-        wpool = srdist.pooled_mean_weight(base.shape[0], device)      # N > 1 ranks: pooled mean over the points of all ranks (caveat B)
+        self._mark('eikonal issued')
+        wpool = srdist.pooled_mean_weight(n_base, device)      # N > 1 ranks: pooled mean over the points of all ranks (caveat B)
         if wpool is not None:
             grad_loss = grad_loss * wpool
         total_loss = total_loss + grad_loss * self.conf.get_float('grad_weight')
@@ -465,14 +524,20 @@ class OptimNetwork(nn.Module):
 
         # --- deformation regulariser (network.py:565-582)
         if use_regu:
-            pts = torch.cat([initTmpPs, self.TmpVs.detach()[regu_idx]], dim=0)
-            def_loss = self.loss_def_regu(pts, d_cond, N, ratio, rand.get('regu_local'))
+            if use_regu_split:
+                defB = self._def_regu_mean(torch.cat([initTmpPs, initTmpPs + nl2[:nr] * 0.01], dim=0), d_cond, N, ratio)
+                nA, nB = regu_idx.shape[0], nr
+                def_loss = defA * (float(nA) / float(nA + nB)) + defB * (float(nB) / float(nA + nB))
+            else:
+                pts = torch.cat([initTmpPs, self.TmpVs.detach()[regu_idx]], dim=0)
+                def_loss = self._def_regu_mean(torch.cat([pts, pts + nl2 * 0.01], dim=0), d_cond, N, ratio)
             self.info['def_loss'] = def_loss.detach()
-            wpool = srdist.pooled_mean_weight(pts.shape[0], device)
+            wpool = srdist.pooled_mean_weight(n_regu, device)
             if wpool is not None:
                 def_loss = def_loss * wpool
             total_loss = total_loss + def_loss * self.conf.get_float('def_regu.weight')
 
+        self._mark('def-regu issued')
         # --- DCT temporal smoothness (network.py:585-593)
         if (poses.requires_grad or trans.requires_grad) and self.conf.get_float('dct_weight') > 0. and self.dctnull is not None:
             dct_loss = self.loss_dct(frame_ids, N)
@@ -483,10 +548,12 @@ class OptimNetwork(nn.Module):
         self.info['color_loss'] = -1.0
         # one host sync for all the gathers below -- taken on the side stream, which waits for the refiner only: the eikonal /
         # def-regu / DCT work queued above keeps the GPU busy while the host learns the count and issues the next branch
+        self._mark('dct issued')
         with torch.cuda.stream(side):
             side.wait_event(refined)
-            conv_idx = check.nonzero(as_tuple=False).view(-1)
+            conv_idx = hostsync.nonzero(check).view(-1)
         main.wait_stream(side)
+        self._mark('converged rays known')
         conv_idx.record_stream(main)
         nconv = conv_idx.numel()
         if nconv > 0:
@@ -500,9 +567,19 @@ class OptimNetwork(nn.Module):
         self.remesh_time = np.floor(self.remesh_time) + float(self.forward_time % self.remesh_intersect) / float(self.remesh_intersect)
         self.info['remesh'] = self.remesh_time
         self.forward_time += 1
+        self._mark('forward issued')
         return total_loss
 
     # ------------------------------------------------------------------ loss terms (a14)
+    def _eikonal_mean(self, pts, ratio):
+        """((|grad f| - 1)^2).mean() over the given points (network.py:547-549)."""
+        pts = pts.detach().requires_grad_()
+        pred = self.sdf(pts, ratio, sdf_only=True)
+        grad = self.sdf.gradient(pts, pred)
+        if step_ops.ENABLED and grad.is_cuda and grad.shape[0] > 0:
+            return step_ops.EikonalLoss.apply(grad)
+        return ((grad.norm(2, dim=-1) - 1) ** 2).mean()
+
     def loss_eikonal(self, base, ratio, noise_local=None, noise_global=None):
         """sample_points (utils.py:74-84) + ((|grad f| - 1)^2).mean()."""
         n_global = base.shape[0] // 6
@@ -510,22 +587,21 @@ class OptimNetwork(nn.Module):
         noise_global = torch.rand(n_global, 3, device=base.device) if noise_global is None else noise_global[:n_global]
         pts = torch.cat([base + noise_local * 0.01, noise_global * (1.8 * 2) - 1.8], dim=0)
         self._eik_pts = pts.detach()
-        pts.requires_grad_()
-        pred = self.sdf(pts, ratio, sdf_only=True)
-        grad = self.sdf.gradient(pts, pred)
-        if step_ops.ENABLED and grad.is_cuda and grad.shape[0] > 0:
-            return step_ops.EikonalLoss.apply(grad)
-        return ((grad.norm(2, dim=-1) - 1) ** 2).mean()
+        return self._eikonal_mean(pts, ratio)
 
-    def loss_def_regu(self, pts, d_cond, N, ratio, noise_local=None):
-        noise_local = torch.randn_like(pts) if noise_local is None else noise_local[:pts.shape[0]]
-        pts = torch.cat([pts, pts + noise_local * 0.01], dim=0).view(1, -1, 3).expand(N, -1, 3)
+    def _def_regu_mean(self, pts, d_cond, N, ratio):
+        """GMRobustError(sum log^2 s(J)).mean() of the translator's Jacobian at `pts` for each of the N frames (network.py:565-582)."""
         from .Deformer import translator_value_jacobian
+        pts = pts.view(1, -1, 3).expand(N, -1, 3)
         _, Jacobs = translator_value_jacobian(self.deformer.defs[0], pts.contiguous(), d_cond, None, ratio)   # forward-mode Jacobian
         if step_ops.ENABLED and Jacobs.is_cuda and Jacobs.numel() > 0:
             return step_ops.DefReguLoss.apply(Jacobs, self.conf.get_float('def_regu.c'))
         s = torch.log(singular_values_3x3(Jacobs))
         return U.GMRobustError((s * s).sum(1), self.conf.get_float('def_regu.c'), True).mean()
+
+    def loss_def_regu(self, pts, d_cond, N, ratio, noise_local=None):
+        noise_local = torch.randn_like(pts) if noise_local is None else noise_local[:pts.shape[0]]
+        return self._def_regu_mean(torch.cat([pts, pts + noise_local * 0.01], dim=0), d_cond, N, ratio)
 
     def loss_dct(self, frame_ids, N):
         klen, Nlen = self.dctnull.shape
@@ -611,12 +687,15 @@ class OptimNetwork(nn.Module):
             self.info['pc_loss']['defconst_loss'] = consistent_loss.detach()
             loss = loss + consistent_loss * cw
         self.TmpOptimizer.zero_grad()
+        self._mark('tb: mask loss issued')
         loss.backward()                              # (deferred weight gradients stay in their buffers until propagateTmpPsGrad flushes)
+        self._mark('tb: inner backward issued')
         if srdist.is_distributed():                  # shared template: exact batch semantics across ranks (every rank joins, zeros if no gradient)
             if self.TmpVs.grad is None:
                 self.TmpVs.grad = torch.zeros_like(self.TmpVs)
             srdist.all_reduce_mean_(self.TmpVs.grad)
         self.TmpOptimizer.step()
+        self._mark('tb: template step issued')
         mnfld_pred = self.sdf(self.TmpVs, ratio, sdf_only=True).view(-1)
         sdf_loss = (mnfld_pred + self.sdfShrinkRadius).abs().mean()
         self.info['pc_loss_sdf'] = sdf_loss.detach()

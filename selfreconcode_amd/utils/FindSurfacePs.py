@@ -19,6 +19,7 @@ import os
 import torch
 
 from .. import _lib
+from .. import hostsync
 from .. import mlp_engine as me
 from .utils import resolve_band_weights
 
@@ -31,7 +32,7 @@ def FindSurfacePs(TmpVs, TmpFaces, frags):
     ks = torch.arange(K, device=inner.device).view(1, 1, 1, K).expand(N, H, W, K)
     index = torch.where(inner, ks, torch.full_like(ks, K)).amin(dim=-1)
     hit = index < K
-    batch_inds, row_inds, col_inds = hit.nonzero(as_tuple=True)
+    batch_inds, row_inds, col_inds = hostsync.nonzero(hit, as_tuple=True)
     sel = index[hit].view(-1, 1)
     finds = torch.gather(pix_to_face[hit], 1, sel).view(-1) % TmpFaces.shape[0]
     ws = torch.gather(bary_coords[hit], 1, sel.view(-1, 1, 1).expand(-1, 1, 3)).view(-1, 3)
