@@ -355,12 +355,12 @@ typedef struct { int32_t ntensors; float beta1, beta2, eps;
                  int32_t pad_[2]; sr_adam_tensor tensor[SR_ADAM_MAX_TENSORS]; } sr_adam_table;
 int sr_adam_step(const sr_adam_table* host_table, void* stream);
 
-/* Cross-stream ordering through device memory (no reference counterpart: the reference runs one stream).
- * hipStreamWaitEvent on this runtime makes the waiting stream wait for EVERYTHING the recording stream holds when the wait is
- * processed, not for the recorded point (tools/stream_latency2.py: a side stream that waits for an event recorded in the middle of
- * a busy main stream starts after the main stream has drained).  _set stores `value` to *flag when the stream reaches it; _wait
- * holds its stream (one sleeping wave) until *flag - value >= 0 in wrapping 32-bit arithmetic, or until timeout_ms has passed, in
- * which case *timed_out (optional) is incremented and the stream proceeds -- the caller must treat that as an error. */
+/* Stream diagnostics (no reference counterpart: the reference runs one stream).
+ * sr_stream_flag_set stores `value` to *flag when its stream reaches it; sr_stream_flag_wait holds its stream (one sleeping wave)
+ * until *flag - value >= 0 in wrapping 32-bit arithmetic or until timeout_ms has passed, in which case *timed_out (optional) is
+ * incremented and the stream proceeds.  An ordering of two streams that does not go through the runtime's events: used by
+ * tools/stream_latency2.py to tell a property of hipStreamWaitEvent from a property of the schedule (the 10+ ms the ray selection
+ * seemed to wait for the main stream turned out to be the host running a whole iteration ahead of the GPU, with either primitive). */
 /* Diagnostics: writes the device's constant 100 MHz counter to *out when the stream reaches this point (timestamps that are
  * comparable across streams, which the runtime's event timestamps are not: tools/host_profile.py). */
 int sr_stream_stamp(uint64_t* out, void* stream);

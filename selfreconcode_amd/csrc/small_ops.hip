@@ -157,9 +157,6 @@ __global__ __launch_bounds__(256) void rows_pad_kernel(const float* __restrict__
   }
 }
 
-// Adam step of up to SR_ADAM_MAX_TENSORS parameter tensors in ONE launch (torch.optim.Adam without weight decay / amsgrad, the
-// optimizer of train.py:139: m <- m + (1 - b1)(g - m);  v <- b2 v + (1 - b2) g g;  p <- p - lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)).
-// torch's multi-tensor implementation issues ~10 launches with 40 us of host time between them at the end of every iteration.
 // ---- cross-stream ordering through device memory (see the header: sr_stream_flag_set / _wait) ----
 __global__ void stream_stamp_kernel(unsigned long long* out) {
   if (threadIdx.x == 0) *out = wall_clock64();
@@ -175,6 +172,9 @@ __global__ void stream_flag_wait_kernel(const unsigned* flag, unsigned value, un
     if (wall_clock64() - t0 > max_ticks) { if (timed_out) atomicAdd(timed_out, 1u); break; }   // never hang the queue: the caller checks the counter
   }
 }
+// Adam step of up to SR_ADAM_MAX_TENSORS parameter tensors in ONE launch (torch.optim.Adam without weight decay / amsgrad, the
+// optimizer of train.py:139: m <- m + (1 - b1)(g - m);  v <- b2 v + (1 - b2) g g;  p <- p - lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)).
+// torch's multi-tensor implementation issues ~10 launches with 40 us of host time between them at the end of every iteration.
 __global__ __launch_bounds__(256) void adam_step_kernel(sr_adam_table t) {
   const sr_adam_tensor T = t.tensor[blockIdx.y];
   const float b2 = t.beta2, eps = t.eps, w1 = t.one_minus_beta1, w2 = t.one_minus_beta2;

@@ -1,16 +1,16 @@
-"""Host round trips of the iteration (mask -> index list) without a blocking runtime wait.
+"""Host round trips of the iteration (bool mask -> index list).
 
-`mask.nonzero()` is a count kernel, a 4-byte device-to-host copy and a *blocking* wait of the calling thread for that copy
-(hipMemcpyWithStream).  Measured on MI355X / ROCm 7.2 inside the training step (tools/host_profile.py): when the host reaches such a
-wait BEFORE the GPU has produced the count, the thread is released ~10 ms after the copy completed (the side stream's event shows the
-result ready at 5.3 ms, the call returns at 18.2 ms), while the same call on an already finished stream returns at once.  Two of
-the iteration's index lists (the seeds of the ray selection, the converged rays after the refiner) are always of the first kind.
-Here the count goes to pinned memory with an asynchronous copy and the host POLLS the event behind it (hipEventQuery, no sleep in
-the runtime), then asks for the index list with the size known (torch.nonzero_static: no synchronisation)."""
+`mask.nonzero()` is a count kernel, a small device-to-host copy and a blocking wait of the calling thread for that copy.  This module
+is the one place the iteration's six round trips go through, so that they can be traced (TRACE: tools/host_profile.py stamps the
+device clock when the count copy is issued and the host clock when the count arrives) and so that the wait can be switched to a
+polling one (SR_HOST_POLL=1: asynchronous copy to pinned memory, hipEventQuery in a loop, then torch.nonzero_static with the size
+known).  Measured on MI355X / ROCm 7.2: both forms return within ~20 us of the count being ready on the GPU; what looked like a
+10 ms wake-up latency of the blocking form was the host running a whole iteration ahead of the GPU (profiles/r03_host_vs_gpu.txt).
+Default: torch's own nonzero (the polling loop occupies a core for nothing)."""
 import os
 import torch
 
-POLL = os.environ.get("SR_HOST_POLL", "1") != "0"
+POLL = os.environ.get("SR_HOST_POLL", "0") != "0"
 TRACE = None        # diagnostics (tools/host_profile.py): callable(label), called when the count copy has been issued and when the host has it
 _pinned = {}
 
@@ -40,7 +40,7 @@ def count_to_host(count):
 
 def nonzero(mask, as_tuple=False):
     """mask.nonzero(as_tuple=...) for a bool CUDA tensor: same rows, same (lexicographic) order."""
-    if not (POLL and mask.is_cuda):
+    if not ((POLL or TRACE is not None) and mask.is_cuda):
         return mask.nonzero(as_tuple=as_tuple)
     n = count_to_host(mask.count_nonzero())
     idx = torch.nonzero_static(mask, size=n)
