@@ -661,6 +661,240 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
   gemm_nt_tile_bf16x3<WM, WN, TM, TN, KTAIL>(g, blockIdx.x, smem3);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same split-bf16 product with 128 x 128 WAVE tiles (256 x 256 per workgroup of 4 waves, one workgroup per CU): the 64 x 64 wave
+// tile above reads six fragment sets from LDS per 24 MFMAs and is LDS-bound (SQ counters: 3.5x the LDS activity per cycle of the fp32
+// kernel, a third of it bank conflicts); a 128 x 128 wave tile reads 24 fragments per 96 MFMAs -- half the LDS bytes per MFMA.  Its 256
+// accumulator registers live in the AGPR half of the unified register file (waves_per_eu(1): one wave per SIMD may use 512 registers), the
+// VGPR half holds two sets of A fragments, two half-sets of B fragments and ONE register stage of global data (a step is 96 MFMAs =
+// ~3000 cycles, longer than the loaded L2 latency).  Schedule of step t (LDS buffer t & 1 holds tile t):
+//   first half : MFMAs of the B blocks 0,1  |  fragments of B blocks 2,3 from LDS;  tile t+1: split, registers -> other LDS buffer
+//   barrier
+//   second half: MFMAs of the B blocks 2,3  |  tile t+2: global memory -> registers;  fragments of tile t+1 (A: other set, B blocks 0,1)
+// One barrier per 96 MFMAs; a wave never waits for an LDS read it has just issued.
+struct Cfg3W {
+  static constexpr int BM = 256, BN = 256;
+  static constexpr int kPlaneA = BM * P3, kPlaneB = BN * P3;                 // elements
+  static constexpr int kBufElems = 3 * (kPlaneA + kPlaneB);
+  static constexpr int kOperandBytes = 2 * kBufElems * 2;
+  static constexpr int kStageBytes = 4 * 32 * (4 * 32 + 4) * 4;              // epilogue: one 32-row band of a wave's tile at a time
+  static constexpr int kLdsBytes = kOperandBytes > kStageBytes ? kOperandBytes : kStageBytes;
+};
+
+template <bool KTAIL>
+__device__ __forceinline__ void gemm_nt_tile_bf16x3_w128(const sr_gemm_args& g, int wg, unsigned char* __restrict__ smem_raw) {
+  using C_ = Cfg3W;
+  unsigned short* lds = reinterpret_cast<unsigned short*>(smem_raw);
+  auto Ap = [&](int buf, int p) -> unsigned short* { return lds + buf * C_::kBufElems + p * C_::kPlaneA; };
+  auto Bp = [&](int buf, int p) -> unsigned short* { return lds + buf * C_::kBufElems + 3 * C_::kPlaneA + p * C_::kPlaneB; };
+  const int tiles_n = (g.N + g.naux_fwd + C_::BN - 1) / C_::BN;
+  const int tiles_m = (g.M + C_::BM - 1) / C_::BM;
+  const int nwg = tiles_m * tiles_n;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, loc = wg / 8;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tn = wg % tiles_n, tm = wg / tiles_n;
+  const int m0 = tm * C_::BM, n0 = tn * C_::BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kh = lane >> 5;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nk = (g.K + BK3 - 1) / BK3;
+  auto a_slot = [](int idx, int& row, int& kq) {                            // idx in [0, 256 * 4): the conflict-free store map of the 64 x 64 version
+    const int u = idx >> 4;
+    row = ((u >> 1) << 3) | ((idx >> 1) & 7);
+    kq = (((u & 1) << 1) | (idx & 1)) * 4;
+  };
+  int arow[4], akq[4];
+  const int akmax = ((g.K + 3) & ~3) - 4;
+  const float* ap[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    a_slot(threadIdx.x + j * 256, arow[j], akq[j]);
+    int gr = m0 + arow[j];
+    gr = gr < g.M ? gr : g.M - 1;
+    ap[j] = g.A + (int64_t)gr * g.lda;
+  }
+  const int brow_l = (threadIdx.x & 7) | ((threadIdx.x >> 4) << 3), bhalf = (threadIdx.x >> 3) & 1;     // rows 0..127; the second load: + 128
+  const unsigned short* bp[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int brow = n0 + brow_l + j * 128;
+    brow = brow < g.N ? brow : g.N - 1;
+    bp[j] = g.B3 + (int64_t)brow * g.ldb3 + bhalf * 8;
+  }
+  // ONE register stage of global data (a second one does not fit next to the fragments: the allocator spills and the kernel runs at 0.7
+  // of this form): tile t+1 is split and written to LDS at the very start of step t and the stage is re-requested with tile t+2 right
+  // behind it, so a load has almost a whole step (~90 MFMAs) to arrive.
+  f32x4 ra[4];
+  u32x4 rb[2][3];
+  auto load = [&](int t) {
+    const int tt = t < nk ? t : nk - 1;                                   // loads past the last step: clamped re-reads, never used
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gk = tt * BK3 + akq[j];
+      ra[j] = *reinterpret_cast<const f32x4*>(ap[j] + (gk < akmax ? gk : akmax));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) rb[j][p] = *reinterpret_cast<const u32x4*>(bp[j] + p * g.plane3 + (int64_t)tt * BK3);
+  };
+  auto store = [&](int buf, int t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 v = ra[j];
+      if (KTAIL) {
+        const int nvalid = g.K - (t * BK3 + akq[j]);
+        v.x = nvalid > 0 ? v.x : 0.f; v.y = nvalid > 1 ? v.y : 0.f; v.z = nvalid > 2 ? v.z : 0.f; v.w = nvalid > 3 ? v.w : 0.f;
+      }
+      unsigned int h0, m0_, l0, h1, m1, l1;
+      split_pair_bf16x3(v.x, v.y, h0, m0_, l0);
+      split_pair_bf16x3(v.z, v.w, h1, m1, l1);
+      const int off = arow[j] * P3 + akq[j];
+      *reinterpret_cast<u32x2*>(Ap(buf, 0) + off) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(Ap(buf, 1) + off) = u32x2{m0_, m1};
+      *reinterpret_cast<u32x2*>(Ap(buf, 2) + off) = u32x2{l0, l1};
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int boff = (brow_l + j * 128) * P3 + bhalf * 8;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(Bp(buf, p) + boff) = rb[j][p];
+    }
+  };
+  const int a_off = (wm * 128 + li) * P3 + kh * 8, b_off = (wn * 128 + li) * P3 + kh * 8;
+  // fragments of one PAIR of 32-row blocks (pair 0: blocks 0,1; pair 1: blocks 2,3), three planes
+  auto read_a = [&](int buf, int pair, bf16x8_t (&f)[3][2]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) f[p][i] = *reinterpret_cast<const bf16x8_t*>(Ap(buf, p) + a_off + (pair * 2 + i) * 32 * P3);
+  };
+  auto read_b = [&](int buf, int pair, bf16x8_t (&f)[3][2]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) f[p][i] = *reinterpret_cast<const bf16x8_t*>(Bp(buf, p) + b_off + (pair * 2 + i) * 32 * P3);
+  };
+  // one quarter of the wave tile (A pair pa x B pair pb): six products, product-outer / accumulator-inner -- dependent MFMAs are 4 apart
+  auto mfma_quarter = [&](const bf16x8_t (&fa)[3][2], const bf16x8_t (&fb)[3][2], int pa, int pb) {
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[pa * 2 + i][pb * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]][i], fb[PB[q]][j], acc[pa * 2 + i][pb * 2 + j], 0, 0, 0);
+  };
+
+  // Rolling fragment registers: four sets of 24 (A pair 0, A pair 1, B pair 0, B pair 1).  A set is reloaded for the NEXT step as soon
+  // as its last quarter of this step is done, always >= 24 MFMAs before its next use:
+  //   quarter 00 (A0 x B0): read A1, B1 of this step;  split + store tile t+1 into the other LDS buffer
+  //   quarter 01 (A0 x B1): ... store continues                                                        -> A0 free
+  //   barrier  (tile t+1 visible; nobody reads this buffer's tile t any more after quarter 00)
+  //   quarter 10 (A1 x B0): global loads of tile t+2;  read A0 of tile t+1                              -> B0 free
+  //   quarter 11 (A1 x B1): read B0 of tile t+1
+  bf16x8_t fa0[3][2], fa1[3][2], fb0[3][2], fb1[3][2];
+  load(0);
+  store(0, 0);
+  __syncthreads();
+  read_a(0, 0, fa0);
+  read_b(0, 0, fb0);
+  load(1);
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    read_a(cur, 1, fa1);
+    read_b(cur, 1, fb1);
+    store(cur ^ 1, t + 1);
+    load(t + 2);
+    mfma_quarter(fa0, fb0, 0, 0);
+    mfma_quarter(fa0, fb1, 0, 1);
+    // issue order of the first half: fragment reads, then the split arithmetic (~6 VALU per MFMA) with its LDS stores, then the loads
+#pragma unroll
+    for (int i = 0; i < 48; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (i < 22) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+      if (i >= 4 && i < 22) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      if (i >= 22 && i < 32) { __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    read_a(cur ^ 1, 0, fa0);
+    mfma_quarter(fa1, fb0, 1, 0);
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    read_b(cur ^ 1, 0, fb0);
+    mfma_quarter(fa1, fb1, 1, 1);
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i >= 4 && i < 10) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();   // the epilogue reuses the operand buffers
+
+  // Epilogue, one 32-row band of the wave's 128 x 128 tile at a time through the 64 x 64 version's code with TM = 1: a band's rows are
+  // m0 + (wm * 4 + a) * 32 + ..., which that code computes as m0' + wm * 32 + ... with m0' = m0 + wm * 96 + a * 32.
+  float* stage = reinterpret_cast<float*>(smem_raw) + wave * (32 * (4 * 32 + 4));
+  const bool interior = m0 + C_::BM <= g.M && n0 + C_::BN <= (g.mode == SR_EPI_FWD ? g.N : (g.nact_bwd < g.N ? g.nact_bwd : g.N));
+  auto band_epilogue = [&](f32x16 (&band)[1][4], int a) __attribute__((always_inline)) {
+    const int mb = m0 + wm * 96 + a * 32;
+    if (interior) {
+      if (g.mode == SR_EPI_FWD) {
+        switch (g.group) {
+          case 1: epilogue_interior_act<2, 2, 1, 4, 1, SR_EPI_FWD>(g, band, mb, n0, wm, wn, li, kh, stage); break;
+          case 2: epilogue_interior_act<2, 2, 1, 4, 2, SR_EPI_FWD>(g, band, mb, n0, wm, wn, li, kh, stage); break;
+          default: epilogue_interior_act<2, 2, 1, 4, 4, SR_EPI_FWD>(g, band, mb, n0, wm, wn, li, kh, stage); break;
+        }
+      } else {
+        switch (g.group) {
+          case 1: epilogue_interior_act<2, 2, 1, 4, 1, SR_EPI_BWD>(g, band, mb, n0, wm, wn, li, kh, stage); break;
+          case 2: epilogue_interior_act<2, 2, 1, 4, 2, SR_EPI_BWD>(g, band, mb, n0, wm, wn, li, kh, stage); break;
+          default: epilogue_interior_act<2, 2, 1, 4, 4, SR_EPI_BWD>(g, band, mb, n0, wm, wn, li, kh, stage); break;
+        }
+      }
+    } else {
+      switch (g.group) {
+        case 1: epilogue<2, 2, 1, 4, 1>(g, band, mb, n0, wm, wn, li, kh, stage); break;
+        case 2: epilogue<2, 2, 1, 4, 2>(g, band, mb, n0, wm, wn, li, kh, stage); break;
+        default: epilogue<2, 2, 1, 4, 4>(g, band, mb, n0, wm, wn, li, kh, stage); break;
+      }
+    }
+    __syncthreads();      // the next band reuses the staging image
+  };
+  // (four literal copies: the band index must be a constant or the accumulators go through scratch memory)
+#define SR_BAND(A_)                                                                     \
+  do {                                                                                  \
+    f32x16 band[1][4] = {{acc[A_][0], acc[A_][1], acc[A_][2], acc[A_][3]}};             \
+    band_epilogue(band, A_);                                                            \
+  } while (0)
+  SR_BAND(0); SR_BAND(1); SR_BAND(2); SR_BAND(3);
+#undef SR_BAND
+}
+
+template <bool KTAIL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_bf16x3_w128_kernel(sr_gemm_args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3w[];
+  gemm_nt_tile_bf16x3_w128<KTAIL>(g, blockIdx.x, smem3w);
+}
+
 // x -> three bf16 planes (weights, once per optimizer step); columns [cols, ld_dst) are written as zero
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ src, int64_t ld_src, int64_t rows, int cols,
                                                             unsigned short* __restrict__ dst, int64_t ld_dst, int64_t plane) {
@@ -995,6 +1229,26 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
   static const int bf16x3_min_rows = getenv("SR_BF16X3_MIN_ROWS") ? atoi(getenv("SR_BF16X3_MIN_ROWS")) : 8192;
   if (g.B3 && ncols > 32 && g.M >= bf16x3_min_rows) {
     if ((g.ldb3 & 15) || ((uintptr_t)g.B3 & 15) || (g.plane3 & 7) || g.ldb3 < ((g.K + 15) & ~15)) return SR_EINVAL;
+    // SR_BF16X3_TILE=256: 256 x 256 workgroup tiles (128 x 128 per wave).  Alone on the machine it is the faster form (164-185 against
+    // 150-156 TFLOP/s-equivalent on 262144 x 512 x 512), inside the iteration it is not (46.8 against 45.8 ms): one workgroup per CU with
+    // 147 KB of LDS leaves no room for the weight-gradient stream's workgroups, and 87k-row launches are 2.7 rounds of 256 tiles.  So it
+    // is a tuning switch, not the default.
+    static const int tile_sel = getenv("SR_BF16X3_TILE") ? atoi(getenv("SR_BF16X3_TILE")) : 0;
+    const int64_t big_tiles = sr_cdiv(g.M, Cfg3W::BM) * sr_cdiv(ncols, Cfg3W::BN);
+    if (tile_sel == 256) {
+      static bool attr_w = false;
+      if (!attr_w) {
+        if (hipFuncSetAttribute((const void*)gemm_nt_bf16x3_w128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg3W::kLdsBytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)gemm_nt_bf16x3_w128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg3W::kLdsBytes) != hipSuccess)
+          return SR_ELAUNCH;
+        attr_w = true;
+      }
+      if (g.K % BK3)
+        hipLaunchKernelGGL((gemm_nt_bf16x3_w128_kernel<true>), dim3((unsigned)big_tiles), dim3(256), Cfg3W::kLdsBytes, (hipStream_t)stream, g);
+      else
+        hipLaunchKernelGGL((gemm_nt_bf16x3_w128_kernel<false>), dim3((unsigned)big_tiles), dim3(256), Cfg3W::kLdsBytes, (hipStream_t)stream, g);
+      return sr_launch_status();
+    }
     using C3 = Cfg3<2, 2, 2, 2>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -443,3 +443,14 @@ def test_bf16x3_gemm_is_fp32_accurate():
         if nfill:
             assert torch.equal(outs["bf16x3"][:, N:N + nfill], outs["f32"][:, N:N + nfill])
     print("errors / sum|a||b| (fp32 MFMA, bf16x3):", worst)
+
+
+def test_bf16x3_wide_wave_tile_variant_in_a_subprocess():
+    """SR_BF16X3_TILE=256 (128 x 128 wave tiles, accumulators in AGPRs) is read once per process: the accuracy test above is re-run
+    under it in a child process (ragged shapes included: edge tiles go through the generic epilogue band by band)."""
+    import os, subprocess, sys
+    env = dict(os.environ, SR_BF16X3_TILE="256")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_bf16x3_gemm_is_fp32_accurate"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "1 passed" in r.stdout
