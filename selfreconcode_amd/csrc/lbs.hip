@@ -80,15 +80,27 @@ struct FramePass {
   }
 };
 
+// 16 outputs per workgroup, 16 lanes per output: lane l sums the partial rows l, l + 16, ... in double, then the 16 sums are folded
+// in a fixed order (a fixed function of nblocks alone: bit-reproducible).  One thread per output (the first version) was 512
+// dependent loads in a row: 65 us for 3.5 MB.
 __global__ __launch_bounds__(256) void lbs_reduce_partials(const float* __restrict__ partials, int nblocks, int nframes,
                                                             float* __restrict__ Abar, float* __restrict__ tbar) {
   const int per = NJ * 12 + 3, n = nframes * per;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partials[(int64_t)b * n + i];
+  const int o = threadIdx.x & 15, l = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + o;
+  double s = 0.0;
+  if (i < n)
+    for (int b = l; b < nblocks; b += 16) s += (double)partials[(int64_t)b * n + i];
+  __shared__ double fold[16][17];
+  fold[l][o] = s;
+  __syncthreads();
+  if (l == 0 && i < n) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += fold[k][o];
     const int f = i / per, e = i % per;
-    if (e < NJ * 12) { if (Abar) Abar[(int64_t)f * NJ * 12 + e] = (float)s; }
-    else if (tbar) tbar[f * 3 + (e - NJ * 12)] = (float)s;
+    if (e < NJ * 12) { if (Abar) Abar[(int64_t)f * NJ * 12 + e] = (float)t; }
+    else if (tbar) tbar[f * 3 + (e - NJ * 12)] = (float)t;
   }
 }
 
@@ -350,7 +362,7 @@ static int lbs_bwd_launch(K kernel, const sr_lbs_args* a, float* Abar, float* tr
   const bool want = Abar || transbar;
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, *a, args..., Abar != nullptr, transbar != nullptr, partials);
   if (want)
-    hipLaunchKernelGGL(lbs_reduce_partials, dim3(sr_cdiv(a->nframes * (NJ * 12 + 3), 256)), dim3(256), 0, (hipStream_t)stream, partials, grid, a->nframes,
+    hipLaunchKernelGGL(lbs_reduce_partials, dim3(sr_cdiv(a->nframes * (NJ * 12 + 3), 16)), dim3(256), 0, (hipStream_t)stream, partials, grid, a->nframes,
                        Abar, transbar);
   return sr_launch_status();
 }
