@@ -340,7 +340,9 @@ int sr_rows_frame_sum(const float* X, int64_t ldx, int64_t P, int32_t E, const i
 #define SR_PACK_MAX_LAYERS 16
 typedef struct { const float* v; const float* g; float* W; float* WT; float* norms; int32_t N, K; int64_t ldw, ldwt; } sr_pack_layer;
 typedef struct { int32_t nlayers; sr_pack_layer layer[SR_PACK_MAX_LAYERS]; } sr_pack_table;
-typedef struct { const float* dW; int64_t lddw; const float* v; const float* g; const float* norms; float* gv; float* gg; int32_t N, K, accumulate; } sr_unpack_layer;
+typedef struct { const float* dW; int64_t lddw; const float* v; const float* g; const float* norms; float* gv; float* gg;
+                 const float* db; float* gb;   /* optional: bias gradient gb[n] += db[n] (n < N) in the same launch */
+                 int32_t N, K, accumulate, pad_; } sr_unpack_layer;
 typedef struct { int32_t nlayers; sr_unpack_layer layer[SR_PACK_MAX_LAYERS]; } sr_unpack_table;
 int sr_pack_weights(const sr_pack_table* host_table, void* stream);
 int sr_unpack_grads(const sr_unpack_table* host_table, void* stream);

@@ -81,8 +81,8 @@ class SrPackTable(ctypes.Structure):
 
 
 class SrUnpackLayer(ctypes.Structure):
-    _fields_ = [("dW", _vp), ("lddw", _i64), ("v", _vp), ("g", _vp), ("norms", _vp), ("gv", _vp), ("gg", _vp), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
-                ("accumulate", ctypes.c_int32)]
+    _fields_ = [("dW", _vp), ("lddw", _i64), ("v", _vp), ("g", _vp), ("norms", _vp), ("gv", _vp), ("gg", _vp), ("db", _vp), ("gb", _vp),
+                ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
 SR_ADAM_MAX_TENSORS = 64

@@ -120,6 +120,8 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(sr_unpack_table t) {
   const sr_unpack_layer L = t.layer[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = gridDim.x * (blockDim.x >> 6);
+  if (L.gb && blockIdx.x == 0)                                   // bias gradient of the layer, accumulated in place
+    for (int n = threadIdx.x; n < L.N; n += blockDim.x) L.gb[n] += L.db[n];
   for (int n = wave; n < L.N; n += nwaves) {
     const float* d = L.dW + (int64_t)n * L.lddw;
     float* gv = L.gv + (int64_t)n * L.K;
@@ -292,7 +294,7 @@ int sr_unpack_grads(const sr_unpack_table* t, void* stream) {
   if (!t || t->nlayers < 1 || t->nlayers > SR_PACK_MAX_LAYERS) return SR_EINVAL;
   for (int l = 0; l < t->nlayers; ++l) {
     const sr_unpack_layer& L = t->layer[l];
-    if (!L.dW || !L.gv || L.N <= 0 || L.K <= 0 || L.lddw < L.K || (L.g && (!L.v || !L.norms || !L.gg))) return SR_EINVAL;
+    if (!L.dW || !L.gv || L.N <= 0 || L.K <= 0 || L.lddw < L.K || (L.g && (!L.v || !L.norms || !L.gg)) || (L.gb && !L.db)) return SR_EINVAL;
   }
   hipLaunchKernelGGL(unpack_grads_kernel, dim3(32, t->nlayers), dim3(256), 0, (hipStream_t)stream, *t);
   return sr_launch_status();

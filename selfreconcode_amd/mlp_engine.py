@@ -774,11 +774,14 @@ def flush_param_grads(only=None):
             L.dW, L.lddw = _lib.ptr(e["dW"]), e["dW"].stride(0)
             L.v, L.g, L.norms = _lib.ptr(vd), (0 if g is None else _lib.ptr(g.detach().contiguous())), (0 if g is None else _lib.ptr(e["norms"]))
             L.gv, L.gg, L.N, L.K, L.accumulate = _lib.ptr(gv), _lib.ptr(gg), v.shape[0], v.shape[1], 1 if acc else 0
-            outs.append((e, v, g, gv, gg, acc, vd))
+            b = e["bias"]
+            fold_bias = b.grad is not None and b.grad.is_contiguous() and b.grad.dtype == torch.float32       # else: the buffer is handed over below
+            L.db, L.gb = (_lib.ptr(e["db"]), _lib.ptr(b.grad)) if fold_bias else (0, 0)
+            outs.append((e, v, g, gv, gg, acc, vd, fold_bias))
         dev = chunk[0]["W"].device
         with torch.cuda.device(dev), torch.no_grad():
             _lib.call("sr_unpack_grads", ctypes.byref(t), torch.cuda.current_stream(dev).cuda_stream)
-        for e, v, g, gv, gg, acc, _ in outs:
+        for e, v, g, gv, gg, acc, _, fold_bias in outs:
             if acc:
                 pass                                         # added in place
             else:
@@ -786,7 +789,9 @@ def flush_param_grads(only=None):
                 if g is not None:
                     g.grad = gg if g.grad is None else g.grad.add_(gg)
             b = e["bias"]
-            if b.grad is None:                                 # hand the buffer over instead of copying it; a new one is made on demand
+            if fold_bias:
+                torch.autograd.graph.increment_version(b.grad)   # added in place by the launch above
+            elif b.grad is None:                               # hand the buffer over instead of copying it; a new one is made on demand
                 b.grad = e["db"]
                 e["db"] = torch.empty_like(e["db"])
             else:
