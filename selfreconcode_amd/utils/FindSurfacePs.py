@@ -169,8 +169,12 @@ _ERROR_WATCH = {}    # device -> (pinned int32, event) of the previous call's ba
 
 class _RefinerWorkspace:
     def __init__(self, dev, cap, ev, times_cap):
-        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        i = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+        if os.environ.get("SR_POISON_WORKSPACE") == "1":       # debugging aid: every buffer starts as NaN / -1 (a kernel that reads what no kernel wrote shows up)
+            f = lambda *shape: torch.full(shape, float("nan"), dtype=torch.float32, device=dev)
+            i = lambda *shape: torch.full(shape, -1, dtype=torch.int32, device=dev)
+        else:
+            f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+            i = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
         self.cap, self.times_cap = cap, times_cap
         self.live = torch.zeros(times_cap + 3, dtype=torch.int32, device=dev)
         self.sync = torch.zeros(4, dtype=torch.int32, device=dev)            # [0] chain barrier counter, [1] barrier-failure flag

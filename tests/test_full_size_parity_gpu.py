@@ -532,6 +532,11 @@ def test_full_size_stream_schedules_agree(stage):
         assert torch.equal(dbg_b['batch_inds'], dbg_c['batch_inds']) and torch.equal(dbg_b['row_inds'], dbg_c['row_inds'])
         for name, other in (("A repeated", a2), ("B (one stream)", b)):
             diff = [k for k in a1 if a1[k].shape != other[k].shape or not torch.equal(a1[k], other[k])]
+            if diff and name == "A repeated":      # which run is the odd one?  (diagnostics: a third run of the same schedule)
+                a3, _ = run("side", True, True)
+                same23 = all(a2[k].shape == a3[k].shape and torch.equal(a2[k], a3[k]) for k in a2)
+                same13 = all(a1[k].shape == a3[k].shape and torch.equal(a1[k], a3[k]) for k in a1)
+                name += f" (third run: equals the second {same23}, equals the first {same13})"
             assert not diff, (name, diff[:8], [float((a1[k] - other[k]).abs().max()) for k in diff[:8] if a1[k].shape == other[k].shape])
         rep = Report()
         assert a1["TmpPs"].shape == c["TmpPs"].shape
