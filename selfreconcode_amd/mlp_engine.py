@@ -284,6 +284,17 @@ _TN_STREAMS = {}
 _TN_PENDING = set()
 
 
+DEBUG_TN_DELAY_MS = int(os.environ.get("SR_DEBUG_TN_DELAY_MS", "0"))      # race amplifier: hold the weight-gradient stream before every launch
+_DELAY_FLAG = {}
+
+
+def _debug_delay(device, ms):
+    f = _DELAY_FLAG.get(str(device))
+    if f is None:
+        f = _DELAY_FLAG[str(device)] = torch.zeros(2, dtype=torch.int32, device=device)
+    _lib.call('sr_stream_flag_wait', f.data_ptr(), 0x40000000, 0, ms, torch.cuda.current_stream(device).cuda_stream)
+
+
 def _tn_stream(device):
     key = str(device)
     st = _TN_STREAMS.get(key)
@@ -327,6 +338,8 @@ def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_g
                     ready.record(main)                                   # Zbar (and, for a partial first use, the zeroed buffers) are final here
                     side.wait_event(ready)
                     with torch.cuda.stream(side):
+                        if DEBUG_TN_DELAY_MS:
+                            _debug_delay(A0.device, DEBUG_TN_DELAY_MS)
                         _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group, dW=sink[0], db=sink[1], accumulate=sink[2],
                                  shared_machine=TN_HALF_SLABS)
                     Zbar.record_stream(side); X.record_stream(side)      # both may be freed by the main stream's owner before the side stream has read them

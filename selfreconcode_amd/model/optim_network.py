@@ -255,6 +255,21 @@ class OptimNetwork(nn.Module):
         return out
 
     # ------------------------------------------------------------------ rasterisation stand-ins
+    _DELAYS = None
+
+    def _debug_delay(self, tag):
+        """Race amplifier (diagnostics, SR_DEBUG_DELAY="tag:ms,tag:ms"): holds the CURRENT stream for `ms` at the tagged point, so that a
+        missing cross-stream dependency changes the results instead of hiding behind the usual timing (tools/race_amplifier.py)."""
+        cls = type(self)
+        if cls._DELAYS is None:
+            cls._DELAYS = {k: int(v) for k, v in (kv.split(':') for kv in os.environ.get('SR_DEBUG_DELAY', '').split(',') if kv)}
+        ms = cls._DELAYS.get(tag)
+        if ms:
+            from .. import _lib
+            if getattr(self, '_delay_flag', None) is None:
+                self._delay_flag = torch.zeros(2, dtype=torch.int32, device=self.TmpVs.device)
+            _lib.call('sr_stream_flag_wait', self._delay_flag.data_ptr(), 0x40000000, 0, ms, torch.cuda.current_stream().cuda_stream)
+
     def _mark(self, label):
         """Diagnostics: host time + a device-clock stamp on the CURRENT stream (sr_stream_stamp; slot index into self.mark_stamps)."""
         if self.host_marks is not None:
@@ -364,6 +379,7 @@ class OptimNetwork(nn.Module):
         self.sdf.packed_weights(); self.deformer.defs[0].packed_weights()   # the per-step weight packs are made HERE, on the main
         fork = torch.cuda.Event()                                           # stream, before the fork: the side stream reads them
         fork.record(main)
+        self._debug_delay('main_after_fork')
         mlp_engine.PROFILE.overlap = True       # (bench.py's roofline leg: event pairs inside the two-stream window are not kernel durations)
 
         masks = self._silhouette(defTmpVs, cameras_sil, H, W, self.point_radius)
@@ -374,6 +390,7 @@ class OptimNetwork(nn.Module):
 
         with torch.cuda.stream(side):
             side.wait_event(fork)
+            self._debug_delay('side_after_wait')
             with torch.no_grad():
                 if 'frags' in datas:
                     batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(seedVs, self.Tmpfs, datas['frags'])
@@ -418,6 +435,7 @@ class OptimNetwork(nn.Module):
             for t in (batch_inds, row_inds, col_inds, initTmpPs, rays, pixels):
                 t.record_stream(main)
         with torch.cuda.stream(rstream), torch.no_grad():
+            self._debug_delay('refiner_start')
             poses_s, trans_s, d_cond_s, _ = self.dataset.get_grad_parameters(frame_ids, device)
             rev = getattr(self, 'refiner_events', None)
             if rev is not None:                  # bench.py: time the refiner occupies on its stream
@@ -442,6 +460,7 @@ class OptimNetwork(nn.Module):
             # before the refiner waits for them, and they do not wait for the refiner; the gathers happen after the template step,
             # as in the reference
             aux.wait_event(fork)
+            self._debug_delay('aux_after_wait')
             vsel = rand['vert_select'][:TmpVnum] if 'vert_select' in rand else torch.rand(TmpVnum, device=device)
             eik_idx = hostsync.nonzero(vsel < 4096. / float(TmpVnum)).view(-1)
             use_regu = 'def_regu' in self.conf and self.conf.get_float('def_regu.weight') > 0.
@@ -455,6 +474,7 @@ class OptimNetwork(nn.Module):
         # (tools/host_profile.py).  So each term is evaluated as two batches: the refiner-independent one is queued before the main
         # stream waits for the refiner, the ray one after it; the means are recombined with their counts (SPLIT_SAMPLE_TERMS = False:
         # one batch each, as the reference writes it).
+        self._debug_delay('main_before_join')
         main.wait_stream(aux)
         for t in (eik_idx, regu_idx):
             if t is not None:
