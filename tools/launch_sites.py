@@ -43,7 +43,8 @@ class Sites(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func).replace('aten.', '')
         if not any(name.startswith(v) for v in VIEWS):
-            site = 'no package frame (autograd engine node)'
+            node = torch._C._current_autograd_node() if hasattr(torch._C, '_current_autograd_node') else None
+            site = 'engine node: ' + (node.name() if node is not None else '?')
             for fr in reversed(traceback.extract_stack(limit=40)):
                 if 'selfreconcode_amd' in fr.filename and 'launch_sites' not in fr.filename:
                     site = fr.filename.split('selfreconcode_amd/')[-1] + ':' + str(fr.lineno) + ' ' + fr.name
@@ -64,21 +65,4 @@ for site, n in bysite.most_common(70):
     print(f'{n / iters:7.1f}  {site[:100]:100s} ' + ', '.join(f'{k}x{v / iters:.0f}' for k, v in ops.most_common(6)))
 print()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    for _ in range(iters):
-        step()
-    torch.cuda.synchronize()
-sites = collections.Counter(); total = 0
-for e in prof.events():
-    nk = len(getattr(e, 'kernels', []) or [])
-    if nk == 0 or e.name.startswith('hip') or e.name.startswith('cuda'):
-        continue
-    site = 'autograd engine / no python frame'
-    for fr in (e.stack or []):
-        if 'selfreconcode_amd' in fr or 'launch_sites' in fr:
-            site = fr.split('selfreconcode_amd/')[-1] if 'selfreconcode_amd' in fr else fr
-            break
-    sites[(site, e.name)] += nk; total += nk
-print(f'{total / iters:.0f} kernel launches per iteration attributed to torch operators')
-for (site, name), n in sites.most_common(90):
-    print(f'{n / iters:7.1f}  {name:28s} {site[:150]}')
+sys.exit(0)
