@@ -46,6 +46,9 @@ LOSS_FINE = {'color_weight': 1.0, 'normal_weight': 0.1, 'weighted_normal': True,
 STAGES = {
     "coarse": dict(conf=gi.LOSS_COARSE, N=3, SP=2048, n_cube=119, radius=0.006, fids=[21, 7, 30]),
     "fine": dict(conf=LOSS_FINE, N=1, SP=2048, n_cube=170, radius=0.0041, fids=[13]),       # SP comes from conf.sample_pix_num = 6144 (network.py:520)
+    # configs[4]: config_loose.conf at 1080 x 1080.  Against config.conf it changes the schedule, switches the normal loss off
+    # (normal_weight = -0.1, :70) and learns the focal length only (opt_camera: princeple_points = false, T = false, :12-14).
+    "loose1080": dict(conf=dict(gi.LOSS_COARSE, normal_weight=-0.1), N=3, SP=2048, n_cube=119, radius=0.006, fids=[21, 7, 30], HW=1080, learn_cam=("focal",)),
 }
 DRAW_SEED0 = 5000
 PROJ_SEEDS = (7001, 7002)
@@ -70,11 +73,13 @@ def mask_image(N, H, W):
     return m[None].expand(N, H, W).contiguous()
 
 
-def build(stage, H=540, W=540, lbs_shape=(65, 225, 129), F=40, n_cube=None, dtype=torch.float32):
+def build(stage, H=None, W=None, lbs_shape=(65, 225, 129), F=40, n_cube=None, dtype=torch.float32):
     """`dtype`: float32 = the reference as it runs (fixture and timing); float64 = the same modules, same float32-representable inputs,
     evaluated in double (torch's default dtype is switched so that every tensor the reference creates on the way is double too)."""
     cfg = STAGES[stage]
     N = cfg["N"]
+    H = H or cfg.get("HW", 540); W = W or cfg.get("HW", 540)
+    learn_cam = cfg.get("learn_cam", ("focal", "princ", "T"))
     n_cube = n_cube or cfg["n_cube"]
     torch.set_default_dtype(dtype)
     sdf = ref.network.getTmpSdf("cpu", 6, 0.6, 256)
@@ -97,7 +102,8 @@ def build(stage, H=540, W=540, lbs_shape=(65, 225, 129), F=40, n_cube=None, dtyp
             leaf = lambda t: t.to(dtype).clone().requires_grad_(True)
             self.poses = leaf(fx.det_tensor((F, 24, 3), 91, 0.12)); self.trans = leaf(fx.det_tensor((F, 3), 92, 0.04))
             self.conds = [leaf(fx.det_tensor((F, 128), 93, 0.1)), leaf(fx.det_tensor((F, 256), 94, 0.1))]
-            self.focal = leaf(torch.tensor([1.2 * W, 1.2 * W])); self.princ = leaf(torch.tensor([W / 2.0, H / 2.0])); self.T = leaf(torch.tensor([0., 0.1, 2.4]))
+            cam = lambda name, t: leaf(t) if name in learn_cam else t.to(dtype)
+            self.focal = cam("focal", torch.tensor([1.2 * W, 1.2 * W])); self.princ = cam("princ", torch.tensor([W / 2.0, H / 2.0])); self.T = cam("T", torch.tensor([0., 0.1, 2.4]))
             self.R = orc.quat2mat(torch.tensor([[0., 0., 1., 0.]])).to(dtype)
 
         def get_grad_parameters(self, idxs, device):
@@ -252,9 +258,11 @@ def run(stage, do_time=False, small=False, dtype=torch.float64, write=True):
                 V_step=(net.TmpVs.detach() - V0)[::23], V_step_digest=param_digest(net.TmpVs.detach() - V0, 11),
                 bi=net.batch_inds.to(torch.int16), rows=net.row_inds.to(torch.int16), cols=net.col_inds.to(torch.int16), g_TmpPs=g_tmpps,
                 sel_bi=refined['bi'].to(torch.int16), sel_rays=refined['rays'], sel_p0=refined['p0'], sel_p1=refined['p1'], sel_check=refined['check'], cam_pos=refined['cam_pos'],
-                **{'L_' + k: np.array(info[k]) for k in ('grad_loss', 'def_loss', 'dct_loss', 'color_loss', 'normal_loss', 'offset_loss', 'pc_loss_sdf')},
+                **{'L_' + k: np.array(info[k]) for k in ('grad_loss', 'def_loss', 'dct_loss', 'color_loss', 'normal_loss', 'offset_loss', 'pc_loss_sdf') if k in info},
                 L_mask_loss=np.array(info['pc_loss']['mask_loss']), L_defconst_loss=np.array(info['pc_loss']['defconst_loss']),
-                g_poses=ds.poses.grad, g_trans=ds.trans.grad, g_dcond=ds.conds[0].grad, g_focal=ds.focal.grad, g_princ=ds.princ.grad, g_T=ds.T.grad)
+                normal_weight=np.array(net.conf.get_float('normal_weight')), learn_cam=np.array([int(t.requires_grad) for t in (ds.focal, ds.princ, ds.T)]),
+                g_poses=ds.poses.grad, g_trans=ds.trans.grad, g_dcond=ds.conds[0].grad,
+                **{'g_' + n: t.grad for n, t in (('focal', ds.focal), ('princ', ds.princ), ('T', ds.T)) if t.requires_grad})
     for tag, params in (("sdf", sp), ("tr", tp), ("rn", rp)):
         for k, (name, p) in enumerate(params.items()):
             arrs[f"d_{tag}.{name}"] = param_digest(p.grad, 100 * k)
@@ -270,7 +278,8 @@ def run(stage, do_time=False, small=False, dtype=torch.float64, write=True):
         times = []
         for rep in range(3):
             for p in list(net.parameters()) + [ds.poses, ds.trans, ds.conds[0], ds.conds[1], ds.focal, ds.princ, ds.T]:
-                p.grad = None
+                if p.requires_grad:
+                    p.grad = None
             tm = {}
             net.maskRender.timers = net.pcRender.timers = tm
             t0 = time.perf_counter()
@@ -288,7 +297,7 @@ def run(stage, do_time=False, small=False, dtype=torch.float64, write=True):
 
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if not a.startswith("--")]
-    stages = ["coarse", "fine"] if (not which or which[0] == "both") else [which[0]]
+    stages = ["coarse", "fine"] if (not which or which[0] == "both") else [which[0]]           # (loose1080: by name)
     small = "--small" in sys.argv
     recs = []
     for st in stages:
