@@ -43,7 +43,11 @@ RATIO = {'sdfRatio': 1.0, 'deformerRatio': 0.62, 'renderRatio': 1.0}
 LOSS_FINE = {'color_weight': 1.0, 'normal_weight': 0.1, 'weighted_normal': True, 'grad_weight': 1., 'offset_weight': 0.,
              'def_regu': {'weight': 0.07, 'c': 0.5}, 'dct_weight': 4., 'sample_pix_num': 6144,
              'pc_weight': {'weight': 10., 'laplacian_weight': -1., 'edge_weight': -10., 'norm_weight': -0.001, 'def_consistent': {'weight': 0.1, 'c': 0.01}}}
+LOSS_MEDIUM = {'color_weight': 1.0, 'normal_weight': 0.1, 'weighted_normal': True, 'grad_weight': 1., 'offset_weight': 0.,          # config.conf:84-104
+               'def_regu': {'weight': 0.1, 'c': 0.5}, 'dct_weight': 3.,
+               'pc_weight': {'weight': 30., 'laplacian_weight': -1., 'edge_weight': -10., 'norm_weight': -0.001, 'def_consistent': {'weight': 0.2, 'c': 0.01}}}
 STAGES = {
+    "medium": dict(conf=LOSS_MEDIUM, N=2, SP=2048, n_cube=153, radius=0.00465, fids=[9, 27]),      # config.conf:36-42 (batch 2, 289 x 385 x 193 grid -> ~140k vertices)
     "coarse": dict(conf=gi.LOSS_COARSE, N=3, SP=2048, n_cube=119, radius=0.006, fids=[21, 7, 30]),
     "fine": dict(conf=LOSS_FINE, N=1, SP=2048, n_cube=170, radius=0.0041, fids=[13]),       # SP comes from conf.sample_pix_num = 6144 (network.py:520)
     # configs[4]: config_loose.conf at 1080 x 1080.  Against config.conf it changes the schedule, switches the normal loss off
