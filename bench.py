@@ -62,12 +62,15 @@ def frames_per_rank(stage, args, world):
     return args.frames_per_gpu or STAGES[stage]["frames"]
 
 
-def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_low, gemm_events):
+def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_low, gemm_events, timed_lr=None, late_lr=None, frames=None, scene=None):
+    """`timed_lr`: Adam learning rate of the timed region (None: the configuration's own 1e-4, no change after the settle phase);
+    `late_lr`: additionally time the same workload at this later rate of the schedule (secondary record `late_schedule_lr`);
+    `frames`: frames per rank and step (default: frames_per_rank); `scene`: keyword overrides of build_synthetic_scene (image size, config)."""
     from selfreconcode_amd import dist as srdist
     from selfreconcode_amd import mlp_engine
     from selfreconcode_amd.synthetic import build_synthetic_scene
-    FR, RAYS = frames_per_rank(stage, args, world), STAGES[stage]["rays"]
-    net, ds, conf = build_synthetic_scene(device=device, frame_num=max(64, 2 * FR * world), stage=stage, consistent_masks=False)
+    FR, RAYS = frames or frames_per_rank(stage, args, world), STAGES[stage]["rays"]
+    net, ds, conf = build_synthetic_scene(device=device, frame_num=max(64, 2 * FR * world), stage=stage, consistent_masks=False, **(scene or {}))
     params = [p for p in net.parameters() if p.requires_grad]
     net.refiner_stream = args.refiner_stream
     from selfreconcode_amd.utils import FindSurfacePs as _fsp
@@ -102,7 +105,7 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
         state["it"] = it + 1
 
     def barrier():
-        if world > 1:
+        if srdist.is_distributed():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -115,7 +118,7 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
         barrier()
         el = time.perf_counter() - t0
         t = torch.tensor([el], device=device, dtype=torch.float64)
-        if world > 1:
+        if srdist.is_distributed():
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         tot = sum(int(r[0]) for r in conv); cv = sum(int(r[1]) for r in conv)
         return float(t), tot / max(len(conv), 1), cv / max(tot, 1)
@@ -123,19 +126,25 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
     rec = {}
     if not args.noise_observations:
         ds.attach_rendered_observations(net, ratio_of(0))
+    timed_lr = lr0 if timed_lr is None else timed_lr
     if settle > 0:                                                        # phase 2: lr 1e-4
-        for _ in range(max(settle - 30, 0)):
-            step()
-        n = min(30, settle)
-        el, rays, cf = timed(n)
-        rec["regime_lr_config"] = {"lr": lr0, "ms_per_step": round(el / n * 1e3, 3), "rays_converged_frac": round(cf, 4), "steps": n,
-                                   "note": "same workload at the learning rate config.conf gives the first 10 epochs, measured at the end of the settle phase"}
+        if timed_lr == lr0:
+            for _ in range(settle):
+                step()
+        else:
+            for _ in range(max(settle - 30, 0)):
+                step()
+            n = min(30, settle)
+            el, rays, cf = timed(n)
+            rec["regime_lr_config"] = {"lr": lr0, "ms_per_step": round(el / n * 1e3, 3), "rays_converged_frac": round(cf, 4), "steps": n,
+                                       "note": "same workload at the learning rate config.conf starts with (epochs 0-9), measured at the end of the settle phase"}
         if not args.noise_observations:
             ds.attach_rendered_observations(net, ratio_of(state["it"]))
-    for g in opt.param_groups:                                            # phase 3: the schedule's later rate
-        g['lr'] = args.lr
-    for _ in range(settle_low):
-        step()
+    if timed_lr != lr0:
+        for g in opt.param_groups:                                        # phase 3: a later rate of the schedule
+            g['lr'] = timed_lr
+        for _ in range(settle_low):
+            step()
     # remesh phase: exactly one remesh inside the timed window when steps <= interval
     Rm = net.remesh_intersect
     net.forward_time = (-(warmup + steps // 2)) % Rm or Rm
@@ -171,6 +180,20 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
         if net.refiner_events:
             refiner_ms = sum(a.elapsed_time(b) for a, b in net.refiner_events) / steps
         net.remesh_events = net.refiner_events = None
+    if late_lr is not None:          # the same workload at a later rate of the MultiStepLR schedule (more rays converge: a heavier colour / normal branch)
+        net.refiner_stream = args.refiner_stream
+        for g in opt.param_groups:
+            g['lr'] = late_lr
+        if not args.noise_observations:
+            ds.attach_rendered_observations(net, ratio_of(state["it"]))
+        for _ in range(settle_low):
+            step()
+        n = min(steps, 20)
+        net.forward_time = (-(n // 2)) % Rm or Rm
+        el_l, rays_l, cf_l = timed(n)
+        rec["late_schedule_lr"] = {"lr": late_lr, "ms_per_step": round(el_l / n * 1e3, 3), "rays_converged_frac": round(cf_l, 4), "steps": n,
+                                   "note": "same workload after the learning rate has dropped to the MultiStepLR value of epochs 80-129 (config.conf:18-27); the reference runs "
+                                           "its FINE stage at that rate, not this one -- kept because it was the headline of rounds 2-3 (49.8 ms) and because it is the heavier mix"}
     ms = el / steps * 1e3
     rem_each = sum(rem) / len(rem) if rem else None
     rec.update({"ms_per_step": round(ms, 3), "elapsed": el, "ms_per_step_instrumented": None if el_i is None else round(el_i / steps * 1e3, 3), "rays_per_iter": round(rays, 1), "rays_converged_frac": round(cf, 4),
@@ -178,7 +201,7 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
                                                                         "interval": Rm},
                 "ms_per_step_remesh_amortised": None if rem_each is None else round((el * 1e3 - rem_each) / steps + rem_each / Rm, 3),
                 "refiner_ms_per_step": None if refiner_ms is None else round(refiner_ms, 3),
-                "frames_per_gpu": FR, "rays_per_frame": RAYS, "image": [ds.H, ds.W], "prof": prof, "shapes": shapes, "net": net})
+                "frames_per_gpu": FR, "rays_per_frame": RAYS, "image": [ds.H, ds.W], "lr_timed": timed_lr, "prof": prof, "shapes": shapes, "net": net})
     return rec
 
 
@@ -234,6 +257,49 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def seg3d_mc_513_record(device):
+    """BASELINE.json configs[3]: Seg3dLossless + marching cubes on the 33..513 cubic pyramid (train.py:55-61) over the SDF MLP."""
+    from selfreconcode_amd.MCAcc import Seg3dLossless
+    from selfreconcode_amd.model.network import getTmpSdf
+    from selfreconcode_amd.ext import MCGpu
+    from selfreconcode_amd.synthetic import sphere_sdf_params
+    net = getTmpSdf(device, 6, 0.6, 256)
+    net.load_state_dict(sphere_sdf_params(7), strict=True)
+
+    def q(points):
+        with torch.no_grad():
+            return net(points.reshape(-1, 3), 1.0, sdf_only=True).reshape(1, 1, -1)
+    res = [(33,) * 3, (65,) * 3, (129,) * 3, (257,) * 3, (513,) * 3]
+    eng = Seg3dLossless(q, [-0.9] * 3, [0.9] * 3, res, balance_value=0.0, use_cuda_impl=True).to(device)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    vol = eng.forward()                                                     # warm-up (allocator, weight packs)
+    sdf = vol[0, 0].permute(2, 1, 0).contiguous()
+    MCGpu.mc_gpu(sdf, eng.spacing_x, eng.spacing_y, eng.spacing_z, eng.bx, eng.by, eng.bz, 0.)
+    t_seg, t_mc = [], []
+    for _ in range(3):
+        a, b, c = ev(), ev(), ev()
+        a.record()
+        vol = eng.forward()
+        sdf = vol[0, 0].permute(2, 1, 0).contiguous()
+        b.record()
+        verts, faces = MCGpu.mc_gpu(sdf, eng.spacing_x, eng.spacing_y, eng.spacing_z, eng.bx, eng.by, eng.bz, 0.)
+        c.record()
+        torch.cuda.synchronize()
+        t_seg.append(a.elapsed_time(b)); t_mc.append(b.elapsed_time(c))
+    t_seg.sort(); t_mc.sort()
+    nvox, V, F = 513 ** 3, int(verts.shape[0]), int(faces.shape[0])
+    mc_bytes = 4 * nvox + 12 * V + 24 * F                                   # SURVEY 8(d): 4 B / voxel compulsory read + 12 V + 24 F out
+    rec = {"workload": "configs[3]: Seg3dLossless (33^3 .. 513^3, fused 2x upsample + candidate selection) over the SDF MLP + marching cubes at 513^3; median of 3",
+           "seg3d_ms": round(t_seg[1], 3), "queries": int(eng.stats["queries"]), "voxels": nvox, "queries_frac": round(eng.stats["queries"] / nvox, 5),
+           "mc_ms": round(t_mc[1], 3), "mc_vertices": V, "mc_faces": F, "mc_algorithmic_bytes": mc_bytes,
+           "mc_roofline": {"bound": "hbm", "achieved": round(mc_bytes / (t_mc[1] * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                           "frac": round(mc_bytes / (t_mc[1] * 1e-3) / 8e12, 4),
+                           "note": "mc_gpu call as the step makes it (classify, scans, emit, host read of the two counts, result tensors); kernels alone: profiles/"}}
+    del net, eng, vol, sdf
+    gc.collect(); torch.cuda.empty_cache()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,9 +309,11 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: fixed frames per GPU; strong: --global-frames split over the GPUs")
     ap.add_argument("--frames-per-gpu", type=int, default=0, help="weak scaling: frames per rank and step (default: the stage's batch size; 1 at N=8 = configs[2])")
     ap.add_argument("--global-frames", type=int, default=8, help="strong scaling: frames per step over all ranks (8 = configs[2])")
-    ap.add_argument("--lr", type=float, default=1e-4 * 0.333 ** 3, help="Adam learning rate of the timed region (the settle phase runs at config's 1e-4)")
+    ap.add_argument("--lr", type=float, default=None, help="Adam learning rate of the timed region (default: the rate config.conf runs the stage at -- 1e-4 for the "
+                                                           "coarse stage = epochs 0-5, the late rate for the fine stage)")
+    ap.add_argument("--late-lr", type=float, default=1e-4 * 0.333 ** 3, help="the MultiStepLR value of epochs 80-129 of config.conf (fine-stage record, `late_schedule_lr` record)")
     ap.add_argument("--settle", type=int, default=120, help="untimed iterations at lr 1e-4 before the timed region")
-    ap.add_argument("--settle-low", type=int, default=40, help="untimed iterations at --lr before warm-up")
+    ap.add_argument("--settle-low", type=int, default=40, help="untimed iterations at a later rate before it is timed")
     ap.add_argument("--noise-observations", action="store_true", help="uniform-noise colour/normal targets instead of rendered ones (round-1 workload)")
     ap.add_argument("--no-fine", action="store_true", help="skip the fine-stage record of the default single-GPU run")
     ap.add_argument("--refiner-stream", choices=["main", "side"], default="side", help="headline pass: run the refiner concurrently with (side) or after (main) the template branch; the instrumented pass always uses main")
@@ -254,6 +322,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm", choices=["f32", "bf16x3"], default="f32", help="arithmetic of the large forward / backward-data layer GEMMs of the HEADLINE run (default: exact fp32 MFMA)")
     ap.add_argument("--no-bf16x3-record", action="store_true", help="skip the secondary record with the split-bf16 layer GEMMs")
+    ap.add_argument("--no-extra-records", action="store_true", help="skip the late-rate, configs[3] (Seg3d + MC at 513^3), configs[4] (1080 x 1080, config_loose.conf) and strong-scaling-model records")
+    ap.add_argument("--simulate-world", type=int, default=0, help="N=1 only: time the workload ONE rank of this many would run (the replicated template term evaluated on 1/R of the vertices, no collectives)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam (multi-tensor launches) instead of the one-launch FusedAdam")
     ap.add_argument("--no-gemm-events", action="store_true", help="skip the HIP-event pairs around the layer GEMMs (roofline leg) to see their cost")
     ap.add_argument("--shape-log", default=None, help="write the per-(M,N,K) GEMM launch table (events) to this JSON file")
@@ -265,13 +335,24 @@ def main():
     rank, world, device = srdist.init_from_env("cuda")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
+    rccl = srdist.describe()                                  # (a collective: every rank calls it)
+    if args.simulate_world > 1:
+        if world != 1:
+            raise SystemExit("--simulate-world is a single-GPU measurement")
+        srdist.simulate_world((0, args.simulate_world))
 
     from selfreconcode_amd import mlp_engine as _me
     _me.set_gemm_mode(args.gemm)
-    main_rec = run_stage(args.stage, args, rank, world, device, args.steps, args.warmup, args.settle, args.settle_low, not args.no_gemm_events)
+    # The learning rate of a record is the one config.conf runs that stage at: the coarse stage is epochs 0-5, all at 1e-4
+    # (config.conf:16-34); the fine stage starts at epoch 12 and spends epochs 80-129 at 1e-4 * 0.333^3 (the MultiStepLR milestones).
+    lr_of = lambda stage: args.lr if args.lr is not None else (None if stage == "coarse" else args.late_lr)
+    extras = world == 1 and not args.no_extra_records and not args.simulate_world and args.scaling == "weak" and not args.frames_per_gpu
+    main_rec = run_stage(args.stage, args, rank, world, device, args.steps, args.warmup, args.settle, args.settle_low, not args.no_gemm_events,
+                         timed_lr=lr_of(args.stage), late_lr=args.late_lr if (extras and args.stage == "coarse" and args.lr is None) else None)
     net = main_rec.pop("net")
     prof, shapes = main_rec.pop("prof"), main_rec.pop("shapes")
     elapsed = main_rec.pop("elapsed")
+    lr_timed = main_rec["lr_timed"]
 
     # secondary headline: SDF MLP forward throughput (no-grad, 393216 samples per call)
     sdf_gs = 0.0
@@ -289,45 +370,78 @@ def main():
     del net
     gc.collect(); torch.cuda.empty_cache()
 
-    fine_rec = None
-    if world == 1 and args.stage == "coarse" and not args.no_fine and args.scaling == "weak" and not args.frames_per_gpu:
-        fine_rec = run_stage("fine", args, rank, world, device, args.steps, args.warmup, max(args.settle // 2, 0), args.settle_low, False)
+    def strip(r):
         for k in ("net", "prof", "shapes", "elapsed"):
-            fine_rec.pop(k, None)
+            r.pop(k, None)
         gc.collect(); torch.cuda.empty_cache()
+        return r
+
+    fine_rec = None
+    if world == 1 and args.stage == "coarse" and not args.no_fine and args.scaling == "weak" and not args.frames_per_gpu and not args.simulate_world:
+        fine_rec = strip(run_stage("fine", args, rank, world, device, args.steps, args.warmup, max(args.settle // 2, 0), args.settle_low, False, timed_lr=lr_of("fine")))
+        fine_rec["workload"] = "fine stage (1 frame x 6144 rays, 321x417x225 grid, remesh every 120: config.conf:39-48,113) at the MultiStepLR rate of epochs 80-129"
 
     # secondary record: the same workload with the split-bf16 (three bf16 terms per operand, six products, fp32 accumulation) forward /
     # backward-data layer GEMMs -- fp32-equivalent accuracy on the bf16 MFMA pipe; opt-in (SR_GEMM=bf16x3), never the headline
     bf16x3_rec = None
-    if world == 1 and args.gemm == "f32" and not args.no_bf16x3_record:
+    if world == 1 and args.gemm == "f32" and not args.no_bf16x3_record and not args.simulate_world:
         _me.set_gemm_mode("bf16x3")
         try:
-            r = run_stage(args.stage, args, rank, world, device, min(args.steps, 20), args.warmup, max(args.settle // 2, 0), args.settle_low, False)
+            r = strip(run_stage(args.stage, args, rank, world, device, min(args.steps, 20), args.warmup, max(args.settle // 2, 0), args.settle_low, False, timed_lr=lr_of(args.stage)))
         finally:
             _me.set_gemm_mode("f32")
-        for k in ("net", "prof", "shapes", "elapsed"):
-            r.pop(k, None)
         bf16x3_rec = {"dtype": "f32-emulated-bf16x3", "ms_per_step": r["ms_per_step"], "iterations_per_s": round(1e3 / r["ms_per_step"], 4),
                       "rays_converged_frac": r["rays_converged_frac"], "ms_per_step_remesh_amortised": r["ms_per_step_remesh_amortised"],
                       "what": "forward / backward-data layer GEMMs with >= 8192 rows: operands split into three bf16 terms, six products accumulated in fp32 by "
                               "v_mfma_f32_32x32x16_bf16 (error below the fp32 MFMA kernel's, tests/test_mlp_gpu.py); refiner chains, weight-gradient GEMMs and "
                               "small launches stay exact fp32"}
-        gc.collect(); torch.cuda.empty_cache()
+
+    # configs[2] (8 frames over 8 GPUs) cannot be run on one GPU; what CAN be measured here is both ends of its strong-scaling
+    # ratio: the whole 8-frame step on one GPU, and the step ONE rank of 8 would run (1 frame, the replicated template term on 1/8 of
+    # the vertices, no collectives).  Their quotient is the modelled 8-GPU speed-up (all-reduce of 15 MB over xGMI: ~0.2 ms, not in it).
+    strong_rec = seg_rec = loose_rec = None
+    if extras and args.stage == "coarse":
+        short = dict(steps=min(args.steps, 20), warmup=args.warmup, settle=max(args.settle // 3, 0), settle_low=0)
+        r8 = strip(run_stage("coarse", args, rank, world, device, short["steps"], short["warmup"], short["settle"], 0, False, frames=8))
+        r1 = strip(run_stage("coarse", args, rank, world, device, short["steps"], short["warmup"], short["settle"], 0, False, frames=1))
+        srdist.simulate_world((0, 8))
+        try:
+            rs = strip(run_stage("coarse", args, rank, world, device, short["steps"], short["warmup"], short["settle"], 0, False, frames=1))
+        finally:
+            srdist.simulate_world(None)
+        strong_rec = {"workload": "configs[2]: 8 frames x 2048 rays per step (coarse stage, lr 1e-4); measured on ONE GPU",
+                      "ms_8_frames_one_gpu": r8["ms_per_step"], "ms_1_frame_replicated_template_term": r1["ms_per_step"],
+                      "ms_one_rank_of_8": rs["ms_per_step"],
+                      "modelled_speedup_8_gpus": round(r8["ms_per_step"] / rs["ms_per_step"], 2),
+                      "modelled_speedup_8_gpus_without_sharding": round(r8["ms_per_step"] / r1["ms_per_step"], 2),
+                      "remesh_ms_each": rs["remesh"]["ms_each"],
+                      "note": "one_rank_of_8 = 1 frame per step with mean|f(TmpVs)| evaluated on vertices 0::8 (dist.shard_world; the gradient all-reduce restores "
+                              "the full mean); the remesh's SDF queries are sharded the same way on a real group (one all-gather per level) but run in full "
+                              "here; collectives (15 MB all-reduce, ~0.2 ms over xGMI) are not in the model"}
+        seg_rec = seg3d_mc_513_record(device)
+        from selfreconcode_amd.config import loose_config
+        rl = strip(run_stage("coarse", args, rank, world, device, min(args.steps, 20), args.warmup, max(args.settle // 3, 0), 0, False,
+                             scene=dict(H=1080, W=1080, conf=loose_config())))
+        loose_rec = {"workload": "configs[4]: config_loose.conf (normal loss off in the coarse stage, focal length the only learnable camera tensor) at 1080 x 1080, "
+                                 "coarse stage, 3 frames x 2048 rays, lr 1e-4; one GPU (the 8-GPU form shards frames as configs[2])",
+                     "ms_per_step": rl["ms_per_step"], "iterations_per_s": round(1e3 / rl["ms_per_step"], 4), "rays_per_iter": rl["rays_per_iter"],
+                     "rays_converged_frac": rl["rays_converged_frac"], "template_vertices": rl["template_vertices"], "remesh": rl["remesh"], "image": rl["image"]}
     if rank != 0:
         return
     FR, RAYS = main_rec["frames_per_gpu"], STAGES[args.stage]["rays"]
     FR_REF = STAGES[args.stage]["frames"]                      # frames of one reference iteration of this stage (config.conf batch_size)
     shared = os.environ.get("SR_ALL_RANKS_ON_DEVICE0") == "1" and world > 1
     flops_step = (prof.get("flops_total", 0.0) + prof.get("flops_total_tn", 0.0)) / max(args.steps, 1)      # every layer GEMM: forward, backward-data, weight-gradient, refiner chains
+    epochs = {"coarse": "epochs 0-5 of config.conf (train.coarse, :28-34), all of them at lr 1e-4 (:16-27)", "fine": "epochs 12-200 of config.conf (train.fine, :43-48)"}[args.stage]
     out = {
-        "metric": f"train.py-equivalent iterations/sec (540x540, {RAYS} rays/frame x {FR} frame{'s' if FR > 1 else ''} per GPU; Adam lr {args.lr:.3g} = the "
-                  f"MultiStepLR value of epochs 80-130 of config.conf's 1e-4 schedule, see regime_lr_config for lr 1e-4)",
+        "metric": f"train.py-equivalent iterations/sec (540x540, {RAYS} rays/frame x {FR} frame{'s' if FR > 1 else ''} per GPU; {args.stage} stage at Adam lr {lr_timed:.3g})",
         "value": round(args.steps * world * FR / FR_REF / elapsed, 4), "unit": "iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_rec["ms_per_step"],
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32" if args.gemm == "f32" else "f32-emulated-bf16x3", "data": "synthetic",
-        "config": {"workload": f"configs[1]: female-3-casual-like 540x540, {args.stage} stage, {FR} frame(s) x {RAYS} rays per rank, full iteration "
+        "config": {"workload": f"configs[1]: female-3-casual-like 540x540, {args.stage} stage = {epochs}, Adam lr {lr_timed:.3g}, {FR} frame(s) x {RAYS} rays per rank, full iteration "
                                "(template deform + K=50 point-silhouette mask loss + template SGD, mesh rasteriser + seeds + Newton refiner, "
-                               "eikonal/offset/def-regu/DCT/colour/normal, backward, implicit-grad propagation, Adam, one remesh in the timed window)",
+                               "eikonal/offset/def-regu/DCT/colour/normal, backward, implicit-grad propagation, Adam, one remesh in the timed window)"
+                               + (f"; ONE RANK OF A SIMULATED {args.simulate_world}-RANK GROUP (template term on 1/{args.simulate_world} of the vertices, no collectives)" if args.simulate_world > 1 else ""),
                    "scaling_mode": (f"strong: {args.global_frames} frames per step split over {world} rank(s)" if args.scaling == "strong" else
                                     f"weak: {FR} frame(s) per rank and step, {FR * world} per step over {world} rank(s)")
                                    + ("; ALL RANKS SHARE DEVICE 0 (functional run, not a measurement)" if shared else ""),
@@ -337,16 +451,23 @@ def main():
                    "rays_per_iter": main_rec["rays_per_iter"], "rays_converged_frac": main_rec["rays_converged_frac"],
                    "observations": "uniform noise" if args.noise_observations else "rendered from the scene (render_frames), re-rendered after the settle phase",
                    "refiner": {"impl": args.refiner_impl, "stream_headline_pass": args.refiner_stream, "stream_instrumented_pass": "main"},
-                   "optimizer": {"impl": "torch.optim.Adam" if args.torch_adam else "FusedAdam (same update rule, one launch)", "lr_timed": args.lr, "settle_iters_lr_1e-4": args.settle, "settle_iters_lr_timed": args.settle_low},
+                   "optimizer": {"impl": "torch.optim.Adam" if args.torch_adam else "FusedAdam (same update rule, one launch)", "lr_timed": lr_timed, "settle_iters_lr_1e-4": args.settle,
+                                 "settle_iters_lr_timed": args.settle_low if lr_timed != 1e-4 else 0},
                    "rasterisation": "in-repo HIP kernels with pytorch3d 0.4.0 semantics (nearest-face mesh rasteriser -> FindSurfacePs; K=50 nearest-in-z "
                                     "point compositor); pytorch3d itself is third-party and not in the reference repository",
-                   "parallelism": f"frame-parallel dp{world}: one flat grad all-reduce/step (overlapped with the implicit-gradient pass) + template-vertex grad all-reduce"},
+                   "parallelism": f"frame-parallel dp{world}: one flat grad all-reduce/step (overlapped with the implicit-gradient pass) + template-vertex grad all-reduce"
+                                  + ("; replicated template term and remesh queries sharded over the ranks" if world > 1 else "")},
+        "rccl": rccl,
         "remesh": main_rec["remesh"], "ms_per_step_remesh_amortised": main_rec["ms_per_step_remesh_amortised"],
         "ms_per_step_instrumented": main_rec["ms_per_step_instrumented"],
         "refiner_ms_per_step": main_rec["refiner_ms_per_step"],
         "regime_lr_config": main_rec.get("regime_lr_config"),
+        "late_schedule_lr": main_rec.get("late_schedule_lr"),
         "fine_stage": fine_rec,
         "bf16x3": bf16x3_rec,
+        "strong_scaling_model": strong_rec,
+        "seg3d_mc_513": seg_rec,
+        "loose1080": loose_rec,
         "sdf_mlp_gsamples_per_s": round(sdf_gs, 5),
         "hbm": hbm,
         "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel / mlp_chain_kernel (fp32 MFMA 32x32x2 layer GEMM tile code with fused epilogue; the chain kernel runs all layers of the refiner's two networks in one launch on the device-side live-ray count), EVERY launch of the timed region with >= 128 rows and > 32 columns and every chain launch; "
@@ -365,20 +486,21 @@ def main():
                      "note": "event pairs are recorded in a SECOND pass over the same K steps (ms_per_step_instrumented); the headline pass carries no events",
                      "traffic": None},
     }
-    for name in ("r03_pmc_gemm_nt.json", "r02_pmc_gemm_nt.json", "r01_pmc_gemm_nt.json"):       # PMC passes cannot run inside this process; latest committed collection
+    for name in ("r04_pmc_gemm_nt.json", "r03_pmc_gemm_nt.json", "r02_pmc_gemm_nt.json", "r01_pmc_gemm_nt.json"):       # PMC passes cannot run inside this process; latest committed collection
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.isfile(pmc):
             with open(pmc) as fh:
                 t = json.load(fh)
             out["roofline"]["traffic"] = round(t["traffic_bytes_per_launch"])
-            out["roofline"]["traffic_note"] = (f"HBM bytes per launch of the wide-output layer GEMMs, calibrated FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc "
-                                               f"passes (profiles/{name}; algorithmic bytes of the same launches: "
-                                               f"{round(t.get('gemm_nt_wide', {}).get('algorithmic_bytes_per_launch', 0))})")
+            out["roofline"]["traffic_note"] = t.get("traffic_note") or (
+                f"HBM bytes per launch of the wide-output layer GEMMs, calibrated FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc "
+                f"passes (profiles/{name}; algorithmic bytes of the same launches: "
+                f"{round(t.get('gemm_nt_wide', {}).get('algorithmic_bytes_per_launch', 0))})")
             break
     if shapes is not None and args.shape_log:
         with open(args.shape_log, "w") as fh:
             json.dump(shapes, fh, indent=1)
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.simulate_world:
         out["cpu_baseline"] = cpu_baseline_record(args, device)
     print(json.dumps(out), flush=True)
 

@@ -120,3 +120,17 @@ def default_config():
         loss_coarse=_loss(0.5, 2., 60., -10., 0.6),
         loss_medium=_loss(1.0, 3., 30., -1., 0.2),
         loss_fine=_loss(1.0, 4., 10., -1., 0.1, def_regu_w=0.07, sample_pix=6144))
+
+
+def loose_config():
+    """config_loose.conf as a delta of config.conf (the only differences, SURVEY D2: `diff config.conf config_loose.conf`): 600 epochs,
+    milestones [30, 60, 240, 400], medium / fine from epochs 18 / 36, principal point and T not optimised, normal loss of the coarse
+    stage switched off (normal_weight = -0.1)."""
+    c = default_config()
+    c['train']['nepoch'] = 600
+    c['train']['opt_camera'] = Conf(focal_length=True, princeple_points=False, quat=False, T=False)
+    c['train']['scheduler']['milestones'] = [30, 60, 240, 400]
+    c['train']['medium']['start_epoch'] = 18
+    c['train']['fine']['start_epoch'] = 36
+    c['loss_coarse']['normal_weight'] = -0.1
+    return c

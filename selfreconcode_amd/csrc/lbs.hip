@@ -108,9 +108,10 @@ __global__ __launch_bounds__(256) void lbs_reduce_partials(const float* __restri
 // Abar[frame][j] = sum w_j ybar (x) [p;1],  transbar[frame] = sum ybar  (deterministic, see FramePass above).
 __global__ __launch_bounds__(256) void lbs_bwd_kernel(sr_lbs_args g, const float* __restrict__ ybar, float* __restrict__ pbar,
                                                        bool want_A, bool want_t, float* __restrict__ partials) {
-  extern __shared__ float sacc[];                 // 4 waves x nframes x (24*12 + 3)
+  extern __shared__ float sacc[];                 // (waves of the block) x nframes x (24*12 + 3)
   const int per = NJ * 12 + 3;
-  for (int i = threadIdx.x; i < 4 * g.nframes * per; i += blockDim.x) sacc[i] = 0.f;
+  const int nwaves = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < nwaves * g.nframes * per; i += blockDim.x) sacc[i] = 0.f;
   __syncthreads();
   float* wacc = sacc + (threadIdx.x >> 6) * g.nframes * per;      // this wave's accumulator rows
   const bool lane0 = (threadIdx.x & 63) == 0;
@@ -193,8 +194,11 @@ __global__ __launch_bounds__(256) void lbs_bwd_kernel(sr_lbs_args g, const float
   }
   __syncthreads();
   const int n = g.nframes * per;
-  for (int i = threadIdx.x; i < n; i += blockDim.x)                 // the four wave rows, in a fixed order
-    partials[(int64_t)blockIdx.x * n + i] = ((sacc[i] + sacc[n + i]) + sacc[2 * n + i]) + sacc[3 * n + i];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {               // the wave rows, in a fixed order
+    float t = sacc[i];
+    for (int wv = 1; wv < nwaves; ++wv) t += sacc[wv * n + i];
+    partials[(int64_t)blockIdx.x * n + i] = t;
+  }
 }
 
 // Backward of (y, J) = sr_lbs_fwd with its analytic Jacobian, for cotangents ybar [P,3] (nullable) and Jbar [P,3,3]:
@@ -207,9 +211,10 @@ __global__ __launch_bounds__(256) void lbs_bwd_kernel(sr_lbs_args g, const float
 // them emits Abar and replaces (w, grad w) by (e, gam) in the same registers, the second contracts the corners with (e, gam).
 __global__ __launch_bounds__(256) void lbs_jac_bwd_kernel(sr_lbs_args g, const float* __restrict__ ybar, const float* __restrict__ Jbar,
                                                            float* __restrict__ pbar, bool want_A, bool want_t, float* __restrict__ partials) {
-  extern __shared__ float sacc[];                 // 4 waves x nframes x (24*12 + 3)
+  extern __shared__ float sacc[];                 // (waves of the block) x nframes x (24*12 + 3)
   const int per = NJ * 12 + 3;
-  for (int i = threadIdx.x; i < 4 * g.nframes * per; i += blockDim.x) sacc[i] = 0.f;
+  const int nwaves = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < nwaves * g.nframes * per; i += blockDim.x) sacc[i] = 0.f;
   __syncthreads();
   float* wacc = sacc + (threadIdx.x >> 6) * g.nframes * per;
   const bool lane0 = (threadIdx.x & 63) == 0;
@@ -338,8 +343,11 @@ __global__ __launch_bounds__(256) void lbs_jac_bwd_kernel(sr_lbs_args g, const f
   }
   __syncthreads();
   const int n = g.nframes * per;
-  for (int i = threadIdx.x; i < n; i += blockDim.x)                 // the four wave rows, in a fixed order
-    partials[(int64_t)blockIdx.x * n + i] = ((sacc[i] + sacc[n + i]) + sacc[2 * n + i]) + sacc[3 * n + i];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {               // the wave rows, in a fixed order
+    float t = sacc[i];
+    for (int wv = 1; wv < nwaves; ++wv) t += sacc[wv * n + i];
+    partials[(int64_t)blockIdx.x * n + i] = t;
+  }
 }
 }  // namespace
 
@@ -357,10 +365,13 @@ extern "C" int64_t sr_lbs_bwd_workspace_floats(int64_t P, int32_t nframes) {
 template <class K, class... Args>
 static int lbs_bwd_launch(K kernel, const sr_lbs_args* a, float* Abar, float* transbar, float* partials, void* stream, Args... args) {
   const int grid = lbs_bwd_grid(a->P);
-  const size_t lds = (size_t)4 * a->nframes * (NJ * 12 + 3) * sizeof(float);
-  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SR_ELAUNCH;
+  // One accumulator row of nframes x 291 floats per wave of the block (1164 B per frame and wave).  Four waves per block up to 14
+  // frames (<= 64 KB: no attribute call, and room for other streams' GEMM workgroups on the CU); beyond that -- no shipped
+  // configuration: batches are 3 / 2 / 1 frames -- one wave per block (37 KB at the 32-frame limit).
+  const int threads = (size_t)4 * a->nframes * (NJ * 12 + 3) * sizeof(float) <= 64 * 1024 ? 256 : 64;
+  const size_t lds = (size_t)(threads / 64) * a->nframes * (NJ * 12 + 3) * sizeof(float);
   const bool want = Abar || transbar;
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, *a, args..., Abar != nullptr, transbar != nullptr, partials);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, (hipStream_t)stream, *a, args..., Abar != nullptr, transbar != nullptr, partials);
   if (want)
     hipLaunchKernelGGL(lbs_reduce_partials, dim3(sr_cdiv(a->nframes * (NJ * 12 + 3), 16)), dim3(256), 0, (hipStream_t)stream, partials, grid, a->nframes,
                        Abar, transbar);

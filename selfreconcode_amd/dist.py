@@ -20,17 +20,42 @@ def init_from_env(device_type="cuda"):
         device = torch.device("cuda", local)
     else:
         device = torch.device("cpu")
-    if world > 1 and not dist.is_initialized():
+    global _FORCED
+    force = os.environ.get("SR_DIST_FORCE_INIT") == "1"     # world size 1 through the real backend: every collective of the step runs
+    if (world > 1 or force) and not dist.is_initialized():  # over RCCL on a one-GPU box (tests/test_dist_gpu.py, bench.py --rccl-selftest)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         backend = os.environ.get("SR_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
         kw = {"device_id": device} if backend == "nccl" else {}     # binds the communicator to this rank's GPU (RCCL)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        _FORCED = force and world == 1
     return rank, world, device
 
 
+_FORCED = False
+
+
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCED)
+
+
+def describe():
+    """What the collectives of this process run on: backend, world size and -- gathered over the ranks -- each rank's device
+    (index, PCI bus id).  bench.py prints it so that an N-GPU record proves N ranks on N different devices over RCCL."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "world": 1, "devices": None}
+    backend = dist.get_backend()
+    world = dist.get_world_size()
+    if backend == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+        props = torch.cuda.get_device_properties(dev)
+        mine = torch.tensor([dev.index, int(getattr(props, "pci_bus_id", -1)), int(getattr(props, "pci_device_id", -1))], dtype=torch.int64, device=dev)
+    else:
+        mine = torch.tensor([torch.cuda.current_device() if torch.cuda.is_available() else -1, -1, -1], dtype=torch.int64)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "world": world,
+            "devices": [{"rank": r, "device_index": int(t[0]), "pci_bus_id": int(t[1]), "pci_device_id": int(t[2])} for r, t in enumerate(out)]}
 
 
 class GradBucket:
@@ -149,3 +174,56 @@ def pooled_mean_weight(count, device):
 def shard_frames(global_frame_ids, rank, world):
     """rank r takes frames batch[r::R] of the global batch."""
     return global_frame_ids[rank::world]
+
+
+# ------------------------------------------------------------------------------------------------
+# Sharding of the REPLICATED template-sized work (strong scaling, configs[2]: 8 frames over 8 GPUs).  Frames shard by construction; what
+# every rank would otherwise repeat is the template term mean|f(TmpVs)| (network.py:690-694: an SDF forward + backward over all V
+# vertices, ~8 ms of a 29 ms one-frame step) and the SDF queries of the remesh (network.py:292-302).  Both are sums over independent
+# points whose gradients land in parameters that are all-reduced anyway, so rank r takes points r::R (template term) or the r-th
+# contiguous chunk (queries) and the results are combined by the gradient all-reduce / one all-gather.
+SHARD_TEMPLATE_TERMS = os.environ.get("SR_SHARD_TEMPLATE", "1") != "0"
+_SIM_WORLD = None        # (rank, world) of a SIMULATED group: bench.py's "one rank of R" workload record on a single GPU (no collectives)
+
+
+def simulate_world(rank_world):
+    global _SIM_WORLD
+    _SIM_WORLD = None if rank_world is None else (int(rank_world[0]), int(rank_world[1]))
+
+
+def shard_world():
+    """(rank, world) over which the replicated template-sized work is split; (0, 1) = not split."""
+    if not SHARD_TEMPLATE_TERMS:
+        return 0, 1
+    if _SIM_WORLD is not None:
+        return _SIM_WORLD
+    if is_distributed():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def is_simulated():
+    return _SIM_WORLD is not None
+
+
+def chunk_bounds(n, rank, world):
+    """Contiguous chunk `rank` of `n` items split into `world` equal parts (the last ones may be shorter / empty)."""
+    per = (n + world - 1) // world
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per), per
+
+
+def all_gather_chunks(mine, n, per):
+    """`mine`: this rank's chunk (chunk_bounds) of a length-n float vector -> the whole vector on every rank.  RCCL: one
+    all_gather_into_tensor of equal, zero-padded chunks; other backends (gloo has no GPU all-gather): an all-reduce of a zero-filled
+    buffer -- x + 0 is exact, so both give every rank the same bits."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    buf = torch.zeros(world * per, dtype=mine.dtype, device=mine.device)
+    if dist.get_backend() == "nccl":
+        pad = torch.zeros(per, dtype=mine.dtype, device=mine.device)
+        pad[:mine.numel()] = mine.reshape(-1)
+        dist.all_gather_into_tensor(buf, pad)
+    else:
+        buf[rank * per:rank * per + mine.numel()] = mine.reshape(-1)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf[:n]

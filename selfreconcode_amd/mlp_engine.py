@@ -259,15 +259,36 @@ def forward(spec, A0, Ws, bs, group):
     _check_mat(A0, "A0")
     R = A0.shape[0]
     acts, X = [], A0
+    seg = _bias_segments(bs[0], R, group)
     with torch.cuda.device(A0.device):
         for l, L in enumerate(spec.layers):
             _check_mat(Ws[l], f"W{l}")
             C = torch.empty((R, pad4(L.N + L.nfill)), dtype=torch.float32, device=A0.device)
-            _gemm_nt(X, X.stride(0), Ws[l], Ws[l].stride(0), C, C.stride(0), R, L.N, L.K, bs[l], group, L.act, EPI_FWD,
-                     out_scale=L.out_scale, aux=A0 if L.nfill else None, ldaux=A0.stride(0), naux_fwd=L.nfill)
+            if l == 0 and seg is not None:
+                # first layer with one bias row per row segment (frame-major batches whose per-frame code product was hoisted into
+                # the bias): one launch per segment into its row slice -- a K = 39 launch is bound by the 2 KB-per-row write whatever
+                # its row count; every later layer runs ONCE over all the segments
+                S, rs = seg
+                for s in range(S):
+                    Xs, Cs = X[s * rs:(s + 1) * rs], C[s * rs:(s + 1) * rs]
+                    _gemm_nt(Xs, X.stride(0), Ws[l], Ws[l].stride(0), Cs, C.stride(0), rs, L.N, L.K, bs[0][s], group, L.act, EPI_FWD,
+                             out_scale=L.out_scale, aux=A0[s * rs:(s + 1) * rs] if L.nfill else None, ldaux=A0.stride(0), naux_fwd=L.nfill)
+            else:
+                _gemm_nt(X, X.stride(0), Ws[l], Ws[l].stride(0), C, C.stride(0), R, L.N, L.K, bs[l], group, L.act, EPI_FWD,
+                         out_scale=L.out_scale, aux=A0 if L.nfill else None, ldaux=A0.stride(0), naux_fwd=L.nfill)
             acts.append(C)
             X = C
     return acts
+
+
+def _bias_segments(b0, R, group):
+    """-> (S, rows per segment) when the first-layer bias is a matrix [S, N_0] (row segment s of the batch uses bias row s), else None."""
+    if b0 is None or b0.dim() != 2:
+        return None
+    S = b0.shape[0]
+    if S < 1 or R % S or (R // S) % group or b0.stride(1) != 1:
+        raise RuntimeError(f"mlp_engine: segmented first-layer bias {tuple(b0.shape)} does not divide {R} rows of group {group}")
+    return S, R // S
 
 
 # Weight-gradient GEMMs on a stream of their own.  In a reverse sweep dW_l = Zbar_l^T X_{l-1} and the backward-data GEMM
@@ -321,12 +342,13 @@ def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_g
     A0bar_extra = None
     Zbar = Ybar
     A0bar = None
+    seg = _bias_segments(bs[0], R, group) if bs is not None else None
     with torch.cuda.device(A0.device):
         for l in range(nl - 1, -1, -1):
             L = spec.layers[l]
             X = A0 if l == 0 else acts[l - 1]
             if need_param_grad:
-                sink = _deferred_sink(Ws[l], bs[l]) if (DEFERRED_PARAM_GRADS and Ws is not None) else None
+                sink = _deferred_sink(Ws[l], bs[l]) if (DEFERRED_PARAM_GRADS and Ws is not None and not (l == 0 and seg is not None)) else None
                 if sink is None and DEFERRED_PARAM_GRADS and Ws is not None and not Ws[l].requires_grad:
                     e = _ENTRY_BY_PTR.get(Ws[l].data_ptr())
                     if e is not None and any(r() is not None and r().requires_grad for r in e.get("src", ())):
@@ -347,6 +369,15 @@ def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_g
                 elif sink is not None:        # accumulate straight into the per-step gradient buffers (no autograd traffic)
                     _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group, dW=sink[0], db=sink[1], accumulate=sink[2],
                              shared_machine=TN_HALF_SLABS)
+                elif l == 0 and seg is not None:
+                    # segmented first-layer bias: the weight gradient is the sum over the segments (accumulated launch by launch, in
+                    # segment order), the bias gradient one row per segment
+                    S, rs = seg
+                    dWs[0] = torch.empty((L.N, pad4(L.K)), dtype=torch.float32, device=A0.device)
+                    dbs[0] = torch.zeros((S, L.N), dtype=torch.float32, device=A0.device)
+                    for s in range(S):
+                        _gemm_tn(Zbar[s * rs:(s + 1) * rs], Zbar.stride(0), X[s * rs:(s + 1) * rs], X.stride(0), rs, L.N, L.K, pad4(L.K), group,
+                                 dW=dWs[0], db=dbs[0][s], accumulate=s > 0)
                 else:
                     dWs[l], dbs[l] = _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group)
             if l > 0:

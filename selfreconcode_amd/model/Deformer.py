@@ -11,6 +11,7 @@ from ..mlp_engine import MLPSpec, mlp_apply, pad_cols, pad4, pack_linear
 from ..utils.utils import resolve_band_weights
 
 
+BATCH_FRAMES = os.environ.get('SR_BATCH_FRAMES', '1') != '0'             # hoisted path: one batch over all frames instead of one MLP pass per frame
 HOIST_FRAME_CODE = os.environ.get('SR_HOIST_FRAME_CODE', '1') != '0'     # frame-major batches: per-frame code product out of the deformer's first-layer GEMM (MLPTranslator.hoisted_first_layer)
 
 
@@ -20,7 +21,11 @@ _EYE3 = {}
 def _eye3(device):
     e = _EYE3.get(device)
     if e is None:
-        e = _EYE3[device] = torch.eye(3, device=device)
+        # created once, read from every stream afterwards (main, refiner, selection): filled on the host and copied synchronously, so
+        # no stream can see the buffer before its contents
+        e = _EYE3[device] = torch.eye(3).to(device)
+        if e.is_cuda:
+            torch.cuda.current_stream(device).synchronize()
     return e
 
 
@@ -91,6 +96,13 @@ class MLPTranslator(nn.Module):
         if batch_inds is None and HOIST_FRAME_CODE and ps.dim() == 3:
             spec, W0p, Bf = self.hoisted_first_layer(conds)
             Ws, bs = self.packed_weights()
+            if BATCH_FRAMES:
+                # all frames in ONE batch: the first layer runs per frame (its bias is the frame's), every other layer once over
+                # N x V rows -- an 85k-row launch is 10.4 tiles of 128 x 128 per CU (the last, partly filled round costs ~10 % of it),
+                # three times that is 31 per CU; a third of the launches, slab reductions and autograd nodes
+                A0 = embed_rows(ps.reshape(-1, 3), self.multires, ws)
+                self.offset = mlp_apply(spec, A0, [W0p] + Ws[1:], [Bf] + bs[1:]).view(ps.shape[0], ps.shape[1], 3)
+                return ps[..., :3] + self.offset
             outs = []
             for p_f, B_f in zip(ps.unbind(0), Bf.unbind(0)):                   # unbind: ONE backward node (a stack) instead of a zero-fill + copy per frame
                 A0 = embed_rows(p_f, self.multires, ws)
@@ -534,7 +546,8 @@ class TranslatorValueJacobian(torch.autograd.Function):
             if ctx.segment:
                 gcond = ge.reshape(ctx.n_extra, ctx.segment, E).sum(1)
             else:
-                gcond = me.rows_frame_sum(ge, index, ctx.n_extra)            # deterministic (index_add: float atomics)
+                gcond = (me.rows_frame_sum(ge, index, ctx.n_extra) if ctx.n_extra <= 32       # deterministic (index_add: float atomics)
+                         else torch.zeros((ctx.n_extra, E), dtype=ge.dtype, device=ge.device).index_add(0, index, ge))
         return (None, None, xbar.view(ctx.xshape), gcond, None, None, None) + tuple(dWs) + tuple(dbs)
 
 
@@ -549,6 +562,8 @@ def translator_value_jacobian(tr, ps, conds, batch_inds, ratio):
     Ws, bs = tr.packed_weights()
     if batch_inds is None and HOIST_FRAME_CODE and ps.dim() == 3:            # frame-major batch: code product as a per-frame bias
         spec, W0p, Bf = tr.hoisted_first_layer(conds)
+        if BATCH_FRAMES:                                                       # one group-4 batch over all frames (see MLPTranslator.forward)
+            return TranslatorValueJacobian.apply(tr, r, ps.contiguous(), None, None, 0, spec, W0p, *Ws[1:], Bf, *bs[1:])
         ds_, Js_ = [], []
         for p_f, B_f in zip(ps.unbind(0), Bf.unbind(0)):                       # unbind: ONE backward node (a stack) instead of a zero-fill + copy per frame
             d_f, J_f = TranslatorValueJacobian.apply(tr, r, p_f.contiguous(), None, None, 0, spec, W0p, *Ws[1:], B_f, *bs[1:])

@@ -35,7 +35,7 @@ def _band_frequencies(L, device, dtype):
 class PEFunction(torch.autograd.Function):
     """A0[P, pad4(3+6L+E)] = [x | PE_L(x) | extra[index] | 0].  The backward is written with
     differentiable torch ops on the saved OUTPUT (d sin = f cos, d cos = -f sin are again columns
-    of A0), so any derivative order works."""
+    of A0), so any derivative order works (the one-kernel shortcuts are taken only when grad mode is off)."""
 
     @staticmethod
     def forward(ctx, x, wt, L, extra, extra_index, segment=0):
@@ -84,7 +84,10 @@ class PEFunction(torch.autograd.Function):
             elif ctx.segment:                       # rows of one frame are contiguous: plain segmented sum, no atomics
                 gextra = ge.reshape(ctx.n_extra, ctx.segment, E).sum(1)
             else:
-                gextra = (mlp_engine.rows_frame_sum(ge, extra_index, ctx.n_extra).to(g.dtype) if (g.is_cuda and ctx.n_extra <= 32)
+                # raw kernel (deterministic fold) only when nothing differentiates this backward again: under create_graph the
+                # per-frame code's gradient must keep its grad_fn (index_add is differentiable)
+                gextra = (mlp_engine.rows_frame_sum(ge, extra_index, ctx.n_extra).to(g.dtype)
+                          if (g.is_cuda and ctx.n_extra <= 32 and not torch.is_grad_enabled())
                           else torch.zeros((ctx.n_extra, E), dtype=g.dtype, device=g.device).index_add(0, extra_index, ge))
         return gx, None, None, gextra, None, None
 

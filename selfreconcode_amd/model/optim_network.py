@@ -14,6 +14,7 @@ Deliberate differences (all documented in DESIGN.md):
     `datas['frags']` and then go through FindSurfacePs as in the reference;
   * random draws can be injected (`rand=`) so that parity tests feed both sides the same numbers.
 """
+import contextlib
 import os
 
 import time
@@ -35,6 +36,10 @@ from .CameraMine import RectifiedPerspectiveCameras
 
 
 SPLIT_SAMPLE_TERMS = os.environ.get('SR_SPLIT_SAMPLE_TERMS', '0') != '0'    # see forward(): refiner-independent part of the sampled terms first
+# The eikonal term and the deformation regulariser each on a stream of their own (autograd runs a node's backward on the stream of its
+# forward, so their reverse sweeps -- three independent chains of large layer launches with the |f(TmpVs)| sweep -- overlap as well and
+# fill each other's last partial round of tiles).  Tuning switch, see DESIGN.md section 4.
+BRANCH_STREAMS = os.environ.get('SR_BRANCH_STREAMS', '0') != '0'
 _SIDE_STREAMS = {}
 
 
@@ -143,7 +148,16 @@ class OptimNetwork(nn.Module):
     def discretizeSDF(self, ratio, engine=None, balance_value=0.):
         def query_func(points):
             with torch.no_grad():
-                return self.sdf.forward(points.reshape(-1, 3), ratio, sdf_only=True).reshape(1, 1, -1)
+                pts = points.reshape(-1, 3)
+                M = pts.shape[0]
+                rank, world = srdist.shard_world()
+                if world > 1 and srdist.is_distributed() and M >= 4096 * world:
+                    # N ranks: every rank queries its contiguous chunk of the list and one all-gather hands every rank the same
+                    # values (bit-identical replicas of the volume -> identical, deterministic marching cubes on every rank)
+                    lo, hi, per = srdist.chunk_bounds(M, rank, world)
+                    mine = self.sdf.forward(pts[lo:hi].contiguous(), ratio, sdf_only=True).reshape(-1) if hi > lo else pts.new_zeros(0)
+                    return srdist.all_gather_chunks(mine, M, per).reshape(1, 1, -1)
+                return self.sdf.forward(pts, ratio, sdf_only=True).reshape(1, 1, -1)
         if engine is None:
             engine = self.engine
         engine.balance_value = balance_value
@@ -511,6 +525,16 @@ class OptimNetwork(nn.Module):
             debug.update(initTmpPs=initTmpPs, check=check, rays=rays)
 
         # --- eikonal (network.py:543-549; sample_points utils.py:74-84)
+        bstreams = None
+        if BRANCH_STREAMS and not split and not mlp_engine.PROFILE.enabled:
+            bstreams = (self._side_stream(device, 2), self._side_stream(device, 3))
+            joined = torch.cuda.Event()
+            joined.record(main)
+            for st in bstreams:
+                st.wait_event(joined)
+                for t in (initTmpPs, nl, ng):
+                    t.record_stream(st)
+        eik_ctx = torch.cuda.stream(bstreams[0]) if bstreams else contextlib.nullcontext()
         if split:
             eikB_pts = initTmpPs + nl[:nr] * 0.01
             eikB = self._eikonal_mean(eikB_pts, ratio)
@@ -518,27 +542,31 @@ class OptimNetwork(nn.Module):
             grad_loss = eikA * (float(nA) / float(nA + nB)) + eikB * (float(nB) / float(nA + nB))
             self._eik_pts = torch.cat([eikB_pts.detach(), eikA_pts.detach()], dim=0)      # the reference's order: rays, vertices, uniform
         else:
-            base = torch.cat([initTmpPs, self.TmpVs.detach()[eik_idx]], dim=0)
-            pts = torch.cat([base + nl * 0.01, ng * (1.8 * 2) - 1.8], dim=0)
-            self._eik_pts = pts.detach()
-            grad_loss = self._eikonal_mean(pts, ratio)
-        self.info['grad_loss'] = grad_loss.detach()
+            with eik_ctx:
+                base = torch.cat([initTmpPs, self.TmpVs.detach()[eik_idx]], dim=0)
+                pts = torch.cat([base + nl * 0.01, ng * (1.8 * 2) - 1.8], dim=0)
+                self._eik_pts = pts.detach()
+                grad_loss = self._eikonal_mean(pts, ratio)
         self._mark('eikonal issued')
-        wpool = srdist.pooled_mean_weight(n_base, device)      # N > 1 ranks: pooled mean over the points of all ranks (caveat B)
-        if wpool is not None:
-            grad_loss = grad_loss * wpool
-        total_loss = total_loss + grad_loss * self.conf.get_float('grad_weight')
+        if not bstreams:
+            self.info['grad_loss'] = grad_loss.detach()
+            wpool = srdist.pooled_mean_weight(n_base, device)      # N > 1 ranks: pooled mean over the points of all ranks (caveat B)
+            if wpool is not None:
+                grad_loss = grad_loss * wpool
+            total_loss = total_loss + grad_loss * self.conf.get_float('grad_weight')
 
         # --- offset regulariser (network.py:552-560): mean |deformation-MLP offset| on the eikonal sample points; logged without
         # gradient when its weight is 0 (both shipped configs), part of the loss when it is positive
         ow = self.conf.get_float('offset_weight') if 'offset_weight' in self.conf else -1.
+        if bstreams and ow > 0.:
+            main.wait_stream(bstreams[0])        # the term joins the loss on the main stream: the sample points must be there
         if ow > 0.:
             self.deformer.defs[0](self._eik_pts.view(1, -1, 3).expand(N, -1, 3), d_cond, ratio=ratio)
             offset_loss = self.deformer.defs[0].offset.view(-1, 3).norm(p=2, dim=-1).mean()
             total_loss = total_loss + offset_loss * ow
             self.info['offset_loss'] = offset_loss.detach()
         elif ow == 0.:
-            with torch.no_grad():
+            with torch.no_grad(), (torch.cuda.stream(bstreams[0]) if bstreams else contextlib.nullcontext()):      # (logged only: stays with the eikonal samples' stream)
                 self.deformer.defs[0](self._eik_pts.view(1, -1, 3).expand(N, -1, 3), d_cond.detach(), ratio=ratio)
                 self.info['offset_loss'] = self.deformer.defs[0].offset.view(-1, 3).norm(p=2, dim=-1).mean()
 
@@ -549,14 +577,26 @@ class OptimNetwork(nn.Module):
                 nA, nB = regu_idx.shape[0], nr
                 def_loss = defA * (float(nA) / float(nA + nB)) + defB * (float(nB) / float(nA + nB))
             else:
-                pts = torch.cat([initTmpPs, self.TmpVs.detach()[regu_idx]], dim=0)
-                def_loss = self._def_regu_mean(torch.cat([pts, pts + nl2 * 0.01], dim=0), d_cond, N, ratio)
+                with (torch.cuda.stream(bstreams[1]) if bstreams else contextlib.nullcontext()):
+                    if bstreams:
+                        nl2.record_stream(bstreams[1])
+                    pts = torch.cat([initTmpPs, self.TmpVs.detach()[regu_idx]], dim=0)
+                    def_loss = self._def_regu_mean(torch.cat([pts, pts + nl2 * 0.01], dim=0), d_cond, N, ratio)
+            if bstreams:
+                main.wait_stream(bstreams[1])
             self.info['def_loss'] = def_loss.detach()
             wpool = srdist.pooled_mean_weight(n_regu, device)
             if wpool is not None:
                 def_loss = def_loss * wpool
             total_loss = total_loss + def_loss * self.conf.get_float('def_regu.weight')
 
+        if bstreams:                       # the eikonal term joins here (its stream ran under the regulariser's forward)
+            main.wait_stream(bstreams[0])
+            self.info['grad_loss'] = grad_loss.detach()
+            wpool = srdist.pooled_mean_weight(n_base, device)
+            if wpool is not None:
+                grad_loss = grad_loss * wpool
+            total_loss = total_loss + grad_loss * self.conf.get_float('grad_weight')
         self._mark('def-regu issued')
         # --- DCT temporal smoothness (network.py:585-593)
         if (poses.requires_grad or trans.requires_grad) and self.conf.get_float('dct_weight') > 0. and self.dctnull is not None:
@@ -716,8 +756,16 @@ class OptimNetwork(nn.Module):
             srdist.all_reduce_mean_(self.TmpVs.grad)
         self.TmpOptimizer.step()
         self._mark('tb: template step issued')
-        mnfld_pred = self.sdf(self.TmpVs, ratio, sdf_only=True).view(-1)
-        sdf_loss = (mnfld_pred + self.sdfShrinkRadius).abs().mean()
+        rank, world = srdist.shard_world()
+        if world > 1:
+            # mean |f(v)| over ALL V vertices is the same on every rank and its gradient reaches only SDF parameters, which are
+            # averaged over the ranks: rank r sums its vertices r::R and scales by R / V -- the rank mean of that is the full mean
+            # (network.py:690-694), at 1/R of the SDF forward + backward per rank.  (`info` then holds this rank's estimate.)
+            mnfld_pred = self.sdf(self.TmpVs[rank::world], ratio, sdf_only=True).view(-1)
+            sdf_loss = (mnfld_pred + self.sdfShrinkRadius).abs().sum() * (float(world) / float(self.TmpVs.shape[0]))
+        else:
+            mnfld_pred = self.sdf(self.TmpVs, ratio, sdf_only=True).view(-1)
+            sdf_loss = (mnfld_pred + self.sdfShrinkRadius).abs().mean()
         self.info['pc_loss_sdf'] = sdf_loss.detach()
         return sdf_loss * (self.conf.get_float('pc_weight.weight') if 'pc_weight' in self.conf else 60.)
 

@@ -49,7 +49,12 @@ class FusedAdam(torch.optim.Optimizer):
         betas, eps = todo[0][3]['betas'], todo[0][3]['eps']
         if any(t[3]['betas'] != betas or t[3]['eps'] != eps for t in todo):
             raise NotImplementedError("FusedAdam: all parameter groups must share betas and eps")
-        key = tuple((id(p), st['exp_avg'].data_ptr()) for p, _, st, _ in todo)
+        dev = todo[0][0].device
+        if any(p.device != dev for p, _, _, _ in todo):
+            raise RuntimeError("FusedAdam: all parameters must live on one device")
+        # (the table holds raw pointers: a parameter whose storage was swapped under the same Parameter object -- p.data = ...,
+        # module.to() -- or whose state was reloaded must rebuild it)
+        key = tuple((id(p), p.data_ptr(), p.numel(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()) for p, _, st, _ in todo)
         cache = getattr(self, '_tables', None)
         if cache is None or cache[0] != key:
             tables = []
@@ -72,7 +77,6 @@ class FusedAdam(torch.optim.Optimizer):
             if c is None:
                 c = corr[k] = (1.0 - b1 ** k, 1.0 / math.sqrt(1.0 - b2 ** k))
             T.g, T.lr, T.bias1, T.inv_sqrt_bias2 = g.data_ptr(), group['lr'], c[0], c[1]
-        dev = todo[0][0].device
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             for t in cache[1]:

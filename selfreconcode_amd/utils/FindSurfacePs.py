@@ -250,15 +250,18 @@ def _optimize_device_driven(ev, cam, rays, initTmpPs, batch_inds, dthreshold, at
         watch[1].synchronize()
         if int(watch[0][0]) != 0:
             raise _lib.SrError("sr_mlp_chain: the device-wide barrier of the previous refiner call gave up (persistent grid not resident)")
-    # ONE grow-only workspace per (device, stream): capacity = next power of two of the largest ray count seen (the Bernoulli ray
-    # selection changes P every call; 57 KB per row).  It is allocated and only ever used with its stream current, so the caching
-    # allocator may hand a replaced workspace's blocks to that stream again without any cross-stream hazard.
+    # ONE grow-only workspace per (device, stream): capacity = the largest ray count seen + 1/8 headroom, in steps of 1024 rows (the
+    # Bernoulli ray selection changes P every call by a few per cent; 57 KB per row, so a power-of-two rounding of 6145 rays would
+    # hold 0.47 GB).  It is allocated and only ever used with its stream current, so the caching allocator may hand a replaced
+    # workspace's blocks to that stream again without any cross-stream hazard.  A workspace made for ANOTHER stream of this device
+    # is dropped when the stream changes (its blocks go back to that stream's pool; work still queued there is ordered before any reuse).
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.cap < P or ws.times_cap < times:
-        cap = max(1024, 1 << max(P - 1, 0).bit_length(), 0 if ws is None else ws.cap)
+        cap = max(1024, (P + P // 8 + 1023) // 1024 * 1024, 0 if ws is None else ws.cap)
         ws = None
-        _WORKSPACES.pop(key, None)
+        for k in [k for k in _WORKSPACES if k[0] == dev]:
+            _WORKSPACES.pop(k, None)
         ws = _WORKSPACES[key] = _RefinerWorkspace(dev, cap, ev, max(times, 30))
     x0 = initTmpPs.contiguous().float()
     bi = batch_inds.contiguous()

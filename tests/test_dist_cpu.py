@@ -55,6 +55,21 @@ def _worker(rank, world, port, out):
     except RuntimeError:
         raised = True
     assert raised
+    # sharded replicated work (strong scaling): rank r of R evaluates chunk r of the remesh's query list and every rank ends up with the
+    # same whole vector; the template term sums vertices r::R scaled by R / V, whose rank mean is the mean over all vertices
+    assert srdist.shard_world() == (rank, world)
+    for n in (11, 2, 1):                                   # ragged: the last chunk shorter, or empty
+        full = torch.arange(n, dtype=torch.float32) * 0.5 - 2.0
+        lo, hi, per = srdist.chunk_bounds(n, rank, world)
+        got = srdist.all_gather_chunks(full[lo:hi].clone(), n, per)
+        assert torch.equal(got, full), (n, got)
+    f = torch.randn(37, generator=torch.Generator().manual_seed(3))
+    part = f[rank::world].abs().sum() * (float(world) / f.numel())
+    tot = part.clone(); dist.all_reduce(tot); tot /= world
+    assert abs(float(tot) - float(f.abs().mean())) < 1e-6
+    srdist.simulate_world((0, 8))
+    assert srdist.shard_world() == (0, 8) and srdist.is_simulated()
+    srdist.simulate_world(None)
     # by value (numpy): a tensor on a multiprocessing queue travels as a shared-memory handle that dies with this process
     out.put((rank, [p.grad.numpy().copy() for p in params], tv.numpy().copy()))
     dist.destroy_process_group()

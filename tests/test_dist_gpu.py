@@ -63,3 +63,19 @@ def test_two_ranks_x_one_frame_equal_one_rank_x_two_frames(tmp_path):
         if err > 1e-4 or l2 > 1e-4:
             bad.append((k, float(err), float(l2)))
     assert not bad, bad
+
+
+def test_rccl_backend_world_size_one():
+    """backend="nccl" (RCCL) with the communicator bound to the device, at the only world size a one-GPU box allows: every helper of
+    selfreconcode_amd/dist.py (initial broadcast, early / main gradient buffers, template all-reduce, pooled-mean weight, count check,
+    describe) and two real steps with the collectives live (tests/_rccl_worker.py).  The other tests of this file force gloo."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("SR_DIST_BACKEND", "SR_ALL_RANKS_ON_DEVICE0")}
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SR_DIST_FORCE_INIT="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_worker.py")], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["ok"] and rec["rccl"]["world"] == 1 and rec["rccl"]["backend"].startswith("rccl")
