@@ -32,8 +32,10 @@ class Seg3dLossless(nn.Module):
                  visualize=False, debug=False, use_cuda_impl=False, faster=False, use_shadow=False, **kwargs):
         super().__init__()
         self.query_func = query_func
-        self.register_buffer('b_min', torch.as_tensor(b_min).float().view(1, 1, 3))
-        self.register_buffer('b_max', torch.as_tensor(b_max).float().view(1, 1, 3))
+        # (host copies: utils.set_hierarchical_config hands over the previous engine's box, which lives on the GPU; the spacings below
+        # are host scalars and `.to(device)` moves the buffers afterwards)
+        self.register_buffer('b_min', torch.as_tensor(b_min).detach().float().cpu().view(1, 1, 3).clone())
+        self.register_buffer('b_max', torch.as_tensor(b_max).detach().float().cpu().view(1, 1, 3).clone())
         if type(resolutions[0]) is int:
             resolutions = torch.tensor([(r, r, r) for r in resolutions])
         else:

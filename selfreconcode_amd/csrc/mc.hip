@@ -55,6 +55,7 @@ __device__ __forceinline__ float from_next_lane(float x, float next) {
 // wave-wide compare masks, so the owned-edge planes are scalar XORs and a group without a sign change never touches
 // the case table.
 constexpr int MC_CHUNK = 16;
+constexpr int MC_BATCH = 4;      // groups whose loads are in flight together (MC_CHUNK % MC_BATCH == 0)
 constexpr int MC_PLANES = 6;
 
 __global__ __launch_bounds__(256) void mc_classify_kernel(const float* __restrict__ sdf, Dim d, float iso, uint64_t* __restrict__ planes,
@@ -78,39 +79,60 @@ __global__ __launch_bounds__(256) void mc_classify_kernel(const float* __restric
     int k = (int)(c - row * d.NZ), i = (int)(row / d.NY);
     int j = (int)(row - (int64_t)i * d.NY);
     const int64_t gend = (g0 + MC_CHUNK < G) ? g0 + MC_CHUNK : G;
-    bool row_ok = i < d.NX - 1 && j < d.NY - 1;       // c >= total implies i >= NX
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (row_ok) { a0 = sdf[c]; a1 = sdf[c + sx]; a2 = sdf[c + sx + sy]; a3 = sdf[c + sy]; }
-    for (int64_t g = g0; g < gend; ++g, c += 64) {
-      // the group after this one, fetched ahead (also the source of lane 63's k+1 plane)
-      int nk = k + 64, nj = j, ni = i;
-      while (nk >= d.NZ) { nk -= d.NZ; if (++nj == d.NY) { nj = 0; ++ni; } }
-      const bool nrow_ok = ni < d.NX - 1 && nj < d.NY - 1;
-      float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
-      if (nrow_ok) { n0 = sdf[c + 64]; n1 = sdf[c + 64 + sx]; n2 = sdf[c + 64 + sx + sy]; n3 = sdf[c + 64 + sy]; }
-      const float b0 = from_next_lane(a0, n0), b1 = from_next_lane(a1, n1), b2 = from_next_lane(a2, n2), b3 = from_next_lane(a3, n3);
-      const uint64_t I = __ballot(row_ok && k < d.NZ - 1);
-      const uint64_t s0 = __ballot(a0 < iso), s1 = __ballot(a1 < iso), s2 = __ballot(a2 < iso), s3 = __ballot(a3 < iso);
-      const uint64_t s4 = __ballot(b0 < iso), s5 = __ballot(b1 < iso), s6 = __ballot(b2 < iso), s7 = __ballot(b3 < iso);
-      const uint64_t mixed = ((s0 ^ s1) | (s0 ^ s2) | (s0 ^ s3) | (s0 ^ s4) | (s0 ^ s5) | (s0 ^ s6) | (s0 ^ s7)) & I;
-      uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
-      if (mixed) {
-        m0 = (s0 ^ s1) & I; m1 = (s0 ^ s3) & I; m2 = (s0 ^ s4) & I;
-        const int idx = (a0 < iso ? 1 : 0) | (a1 < iso ? 2 : 0) | (a2 < iso ? 4 : 0) | (a3 < iso ? 8 : 0) | (b0 < iso ? 16 : 0) |
-                        (b1 < iso ? 32 : 0) | (b2 < iso ? 64 : 0) | (b3 < iso ? 128 : 0);
-        const uint32_t nt = dTriCount[idx];
-        m3 = __ballot(nt & 1) & I; m4 = __ballot(nt & 2) & I; m5 = __ballot(nt & 4) & I;
+    // MC_BATCH groups are in flight at a time: the 4 x MC_BATCH row loads of the next groups are issued before the first of them is
+    // used (one group ahead -- 4 loads per wave in flight -- left the kernel at 1 TB/s, bound by memory latency, not bandwidth).
+    // q[b] = (k, j, i, interior-row flag) and a[b][0..3] = the four k-plane values of group g + b; slot MC_BATCH of a batch is slot
+    // 0 of the next one (and lane 63's k+1 neighbour of the batch's last group).
+    int qk[MC_BATCH + 1], qj[MC_BATCH + 1], qi[MC_BATCH + 1];
+    bool qok[MC_BATCH + 1];
+    float a[MC_BATCH + 1][4];
+    qk[0] = k; qj[0] = j; qi[0] = i;
+    qok[0] = i < d.NX - 1 && j < d.NY - 1;       // c >= total implies i >= NX
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[0][e] = 0.f;
+    if (qok[0]) { a[0][0] = sdf[c]; a[0][1] = sdf[c + sx]; a[0][2] = sdf[c + sx + sy]; a[0][3] = sdf[c + sy]; }
+    for (int64_t g = g0; g < gend; g += MC_BATCH, c += 64 * MC_BATCH) {
+#pragma unroll
+      for (int b = 1; b <= MC_BATCH; ++b) {
+        int nk = qk[b - 1] + 64, nj = qj[b - 1], ni = qi[b - 1];
+        while (nk >= d.NZ) { nk -= d.NZ; if (++nj == d.NY) { nj = 0; ++ni; } }
+        qk[b] = nk; qj[b] = nj; qi[b] = ni;
+        qok[b] = ni < d.NX - 1 && nj < d.NY - 1 && g + b <= gend;     // (groups past the chunk's last "next" group are never used)
+        const int64_t cb = c + 64 * b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[b][e] = 0.f;
+        if (qok[b]) { a[b][0] = sdf[cb]; a[b][1] = sdf[cb + sx]; a[b][2] = sdf[cb + sx + sy]; a[b][3] = sdf[cb + sy]; }
       }
-      if (lane < MC_PLANES) {
-        const uint64_t mine = lane == 0 ? m0 : lane == 1 ? m1 : lane == 2 ? m2 : lane == 3 ? m3 : lane == 4 ? m4 : m5;
-        planes[g * MC_PLANES + lane] = mine;
+#pragma unroll
+      for (int b = 0; b < MC_BATCH; ++b) {
+        if (g + b >= gend) break;                                      // (wave-uniform)
+        const float a0 = a[b][0], a1 = a[b][1], a2 = a[b][2], a3 = a[b][3];
+        const float b0 = from_next_lane(a0, a[b + 1][0]), b1 = from_next_lane(a1, a[b + 1][1]), b2 = from_next_lane(a2, a[b + 1][2]),
+                    b3 = from_next_lane(a3, a[b + 1][3]);
+        const uint64_t I = __ballot(qok[b] && qk[b] < d.NZ - 1);
+        const uint64_t s0 = __ballot(a0 < iso), s1 = __ballot(a1 < iso), s2 = __ballot(a2 < iso), s3 = __ballot(a3 < iso);
+        const uint64_t s4 = __ballot(b0 < iso), s5 = __ballot(b1 < iso), s6 = __ballot(b2 < iso), s7 = __ballot(b3 < iso);
+        const uint64_t mixed = ((s0 ^ s1) | (s0 ^ s2) | (s0 ^ s3) | (s0 ^ s4) | (s0 ^ s5) | (s0 ^ s6) | (s0 ^ s7)) & I;
+        uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
+        if (mixed) {
+          m0 = (s0 ^ s1) & I; m1 = (s0 ^ s3) & I; m2 = (s0 ^ s4) & I;
+          const int idx = (a0 < iso ? 1 : 0) | (a1 < iso ? 2 : 0) | (a2 < iso ? 4 : 0) | (a3 < iso ? 8 : 0) | (b0 < iso ? 16 : 0) |
+                          (b1 < iso ? 32 : 0) | (b2 < iso ? 64 : 0) | (b3 < iso ? 128 : 0);
+          const uint32_t nt = dTriCount[idx];
+          m3 = __ballot(nt & 1) & I; m4 = __ballot(nt & 2) & I; m5 = __ballot(nt & 4) & I;
+        }
+        if (lane < MC_PLANES) {
+          const uint64_t mine = lane == 0 ? m0 : lane == 1 ? m1 : lane == 2 ? m2 : lane == 3 ? m3 : lane == 4 ? m4 : m5;
+          planes[(g + b) * MC_PLANES + lane] = mine;
+        }
+        if (lane == 0) {
+          vs64[g + b] = __popcll(m0) + __popcll(m1) + __popcll(m2);
+          ts64[g + b] = __popcll(m3) + 2 * __popcll(m4) + 4 * __popcll(m5);
+        }
       }
-      if (lane == 0) {
-        vs64[g] = __popcll(m0) + __popcll(m1) + __popcll(m2);
-        ts64[g] = __popcll(m3) + 2 * __popcll(m4) + 4 * __popcll(m5);
-      }
-      a0 = n0; a1 = n1; a2 = n2; a3 = n3;
-      k = nk; j = nj; i = ni; row_ok = nrow_ok;
+      qk[0] = qk[MC_BATCH]; qj[0] = qj[MC_BATCH]; qi[0] = qi[MC_BATCH]; qok[0] = qok[MC_BATCH];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[0][e] = a[MC_BATCH][e];
     }
   }
 }

@@ -108,6 +108,6 @@ def test_hip_kernels_vs_reference_kernels(dtype, layout):
     # without the volume-sized outputs (what the autograd glue asks for): same point gradients
     _, gg2 = GridSamplerMine.backward(inp, grid, gout, 0, 1, want_grad_input=False)
     _, dg2, dgo2 = GridSamplerMine.dbackward(None, gog, inp, grid, gout, 0, 1, want_grad_input=False)
-    assert torch.equal(gg2, gg)
+    _close(gg2.cpu().numpy(), g[f"{tag}_gg"], tol, "gg (no grad_input)")          # (the channel-last fast path sums the corners in another order: not bit-equal to the general one)
     zero = dict(zip(("di", "dg", "dgo"), GridSamplerMine.dbackward(torch.zeros_like(goi), gog, inp, grid, gout, 0, 1)))
-    assert torch.equal(dg2, zero["dg"]) and torch.equal(dgo2, zero["dgo"])
+    _close(dg2.cpu().numpy(), zero["dg"].cpu().numpy(), tol, "dg (no grad_input)"); _close(dgo2.cpu().numpy(), zero["dgo"].cpu().numpy(), tol, "dgo (no grad_input)")

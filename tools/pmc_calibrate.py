@@ -17,4 +17,14 @@ for M in (524288, 131072):
     torch.cuda.synchronize()
     out.append({"kernel": "gemm_nt_kernel", "M": M, "launches": 4, "read_bytes": M * 512 * 4 + 512 * 512 * 4, "write_bytes": M * 512 * 4})
     del A, C
+# An INDEPENDENT streaming kernel with the same access width (16 bytes per lane, fully coalesced): torch's vectorised copy of a 1 GiB /
+# 256 MiB tensor.  It fixes the counter-to-byte factors WITHOUT assuming anything about the GEMM; the GEMM launches above are then read
+# with those factors (tools/summarize_profile.py), so "measured / algorithmic" of the GEMM is a measurement, not an identity.
+for M in (524288, 131072):
+    src = torch.randn(M, 512, device=dev); dst = torch.empty_like(src)
+    for _ in range(4):
+        torch.mul(src, 1.0, out=dst)          # vectorized_elementwise_kernel<4, ...>: float4 loads and stores (a plain copy_ would be a runtime memcpy)
+    torch.cuda.synchronize()
+    out.append({"kernel": "stream_copy", "M": M, "launches": 4, "read_bytes": M * 512 * 4, "write_bytes": M * 512 * 4})
+    del src, dst
 print(json.dumps(out))

@@ -34,6 +34,8 @@ def collect(d, by_grid=False):
             n = r['Kernel_Name']
             if 'gemm_nt_kernel' in n:      # per tile configuration: <2,2,*,*> are the wide-output launches the shape log records
                 key = 'gemm_nt_kernel' + n[n.index('<'):n.index('>') + 1].replace(' ', '')
+            elif by_grid and ('elementwise_kernel' in n or 'copyBuffer' in n or 'CatArrayBatchedCopy' in n):
+                key = 'stream_copy'                   # calibration pass only: torch's vectorised copy (tools/pmc_calibrate.py)
             else:
                 key = 'gemm_tn_kernel' if 'gemm_tn_kernel' in n else 'mlp_layer_pair_kernel' if 'mlp_layer_pair_kernel' in n else None
             if not key: continue
