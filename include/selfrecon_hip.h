@@ -157,7 +157,8 @@ int sr_mlp_chain(const sr_chain_args* host_args, void* stream);
 
 /* Weight gradient: dW[N, lddw] (+)= sum_r Z[r, 0:N]^T A[r, 0:K], all rows (primal and tangent).
  * Split over r into `splits` slabs in `partial` (>= splits*N*lddw floats, see _workspace_floats),
- * reduced in a fixed order (deterministic).  accumulate != 0 adds into dW. */
+ * reduced in a fixed order (deterministic).  accumulate != 0 adds into dW.  lddw % 4 == 0, dW and partial 16-byte aligned
+ * (the reduction moves float4); columns [K, lddw) of dW are written as 0. */
 typedef struct {
   const float* Z; int64_t ldz;
   const float* A; int64_t lda;

@@ -1158,20 +1158,42 @@ static inline bool tn_narrow(int N, int64_t K) { return K <= 64 && N >= 256; }
 
 // dW = (accumulate ? dW : 0) + sum_s partial[s]; padding columns [K, lddw) are written as 0.  The same launch folds the
 // bias-gradient partials (indices past N * lddw): db = (accumulate ? db : 0) + sum_s db_partial[s].
+// Slabs are added in slab order (deterministic).  Round 4: four elements per thread as 16-byte loads, and the loads of eight slabs are
+// issued before the first of them is added -- the plain loop (`s += partial[p * total + i]`, trip count unknown to the compiler) waited
+// for every slab's load in turn: 22 us for 16-32 slabs of a 512 x 512 gradient, i.e. memory latency x slabs, ninety times per iteration
+// on the weight-gradient stream.  Same order of additions per element, same bits.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int N,
                                                            int K, int64_t lddw, int splits, int accumulate,
                                                            const float* __restrict__ db_partial, float* __restrict__ db) {
   const int64_t total = (int64_t)N * lddw;
-  const int64_t all = total + (db ? N : 0);
+  const int64_t quads = total >> 2;                      // lddw % 4 == 0 (checked by the caller)
+  const int64_t all = quads + (db ? N : 0);
+  const f32x4* __restrict__ p4 = reinterpret_cast<const f32x4*>(partial);
+  f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(dW);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < all; i += (int64_t)gridDim.x * blockDim.x) {
-    if (i < total) {
-      const int col = (int)(i % lddw);
-      float s = 0.f;
-      if (col < K)
-        for (int p = 0; p < splits; ++p) s += partial[(int64_t)p * total + i];
-      dW[i] = (accumulate ? dW[i] : 0.f) + s;
+    if (i < quads) {
+      const int col = (int)((i << 2) % lddw);
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      if (col < K) {
+        const f32x4* src = p4 + i;
+        int p = 0;
+        for (; p + 8 <= splits; p += 8) {
+          f32x4 v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)(p + j) * quads];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; p < splits; ++p) s += src[(int64_t)p * quads];
+        if (col + 1 >= K) s.y = 0.f;                     // columns past K hold whatever the workspace held: the tile kernel never writes them
+        if (col + 2 >= K) s.z = 0.f;
+        if (col + 3 >= K) s.w = 0.f;
+      }
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      if (accumulate) o = d4[i];
+      d4[i] = o + s;
     } else {
-      const int n = (int)(i - total);
+      const int n = (int)(i - quads);
       float s = 0.f;
       for (int p = 0; p < splits; ++p) s += db_partial[(int64_t)p * N + n];
       db[n] = (accumulate ? db[n] : 0.f) + s;
@@ -1387,6 +1409,7 @@ int sr_mlp_gemm_tn(const sr_gemm_tn_args* a, void* stream) {
   if (!a || !a->dW || !a->partial || a->R < 0 || a->N <= 0 || a->K <= 0 || a->splits < 1) return SR_EINVAL;
   if (a->R > 0 && (!a->Z || !a->A)) return SR_EINVAL;
   if ((a->ldz & 3) || (a->lda & 3) || ((uintptr_t)a->Z & 15) || ((uintptr_t)a->A & 15) || a->lddw < a->K) return SR_EINVAL;
+  if ((a->lddw & 3) || ((uintptr_t)a->dW & 15) || ((uintptr_t)a->partial & 15)) return SR_EINVAL;      // the slab reduction moves float4
   if ((a->db != nullptr) != (a->db_partial != nullptr) || (a->db && a->group < 1)) return SR_EINVAL;
   const bool narrow = tn_narrow(a->N, a->lddw);        // (the same rule as the workspace query: it sized `splits`)
   const int tiles = narrow ? (int)sr_cdiv(a->N, 256) : (int)(sr_cdiv(a->N, 128) * sr_cdiv(a->K, 128));
@@ -1402,7 +1425,7 @@ int sr_mlp_gemm_tn(const sr_gemm_tn_args* a, void* stream) {
       hipLaunchKernelGGL((gemm_tn_kernel<128, 128>), dim3(tiles * a->splits), dim3(256), Square::kLdsFloats * sizeof(float), (hipStream_t)stream, *a,
                          rows_per_split);
   }
-  const int64_t total = (int64_t)a->N * a->lddw + (a->db ? a->N : 0);
+  const int64_t total = (int64_t)a->N * a->lddw / 4 + (a->db ? a->N : 0);
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(sr_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, a->partial, a->dW,
                      a->N, a->K, a->lddw, a->R > 0 ? a->splits : 0, a->accumulate, a->db_partial, a->db);
   return sr_launch_status();

@@ -151,7 +151,8 @@ class OptimNetwork(nn.Module):
                 pts = points.reshape(-1, 3)
                 M = pts.shape[0]
                 rank, world = srdist.shard_world()
-                if world > 1 and srdist.is_distributed() and M >= 4096 * world:
+                if srdist.is_distributed() and not srdist.is_simulated() and srdist.SHARD_TEMPLATE_TERMS and M >= 4096 * world:
+                    # (also at a forced world size of 1 -- SR_DIST_FORCE_INIT, the RCCL self-test: one chunk, one all-gather)
                     # N ranks: every rank queries its contiguous chunk of the list and one all-gather hands every rank the same
                     # values (bit-identical replicas of the volume -> identical, deterministic marching cubes on every rank)
                     lo, hi, per = srdist.chunk_bounds(M, rank, world)

@@ -34,11 +34,17 @@ def main():
     w = srdist.pooled_mean_weight(41, device)
     assert abs(float(w) - 1.0) < 1e-7
     srdist.assert_same_across_ranks(85111, "vertex count")
+    full = torch.arange(10007, dtype=torch.float32, device=device) * 0.25 - 3.0        # the remesh's sharded query list: chunk -> all_gather_into_tensor
+    lo, hi, per = srdist.chunk_bounds(full.numel(), rank, world)
+    assert torch.equal(srdist.all_gather_chunks(full[lo:hi].clone(), full.numel(), per), full)
+    gathers = []
+    real_gather = srdist.all_gather_chunks
+    srdist.all_gather_chunks = lambda mine, n, per: (gathers.append(n), real_gather(mine, n, per))[1]
     # --- the real step with the collectives live (template all-reduce inside forward, count check after the remesh, early + main buffers)
     from selfreconcode_amd import mlp_engine
     from selfreconcode_amd.optim import FusedAdam
     from selfreconcode_amd.synthetic import build_synthetic_scene
-    net, ds, conf = build_synthetic_scene(device=device, frame_num=40, H=128, W=128, resolutions=[(15, 21, 9), (29, 41, 17), (57, 81, 33)],
+    net, ds, conf = build_synthetic_scene(device=device, frame_num=40, H=128, W=128, resolutions=[(15, 21, 9), (29, 41, 17), (57, 81, 33), (113, 161, 65)],
                                           lbs_volume_shape=(17, 57, 33))
     mlp_engine.set_deferred_param_grads(True)
     params = [p for p in net.parameters() if p.requires_grad]
@@ -59,7 +65,8 @@ def main():
     dist.barrier()
     torch.cuda.synchronize()
     assert all(l == l and abs(l) < 1e6 for l in losses), losses
-    print(json.dumps({"ok": True, "rccl": desc, "losses": losses}), flush=True)
+    assert gathers and max(gathers) >= 4096, gathers                                    # the remesh of the first step went through the all-gather
+    print(json.dumps({"ok": True, "rccl": desc, "losses": losses, "gathered_query_lists": gathers}), flush=True)
     dist.destroy_process_group()
 
 

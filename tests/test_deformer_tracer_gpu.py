@@ -147,6 +147,42 @@ def test_translator_forward_mode_jacobian_and_its_reverse():
     close(d2, d2o, atol=2e-6)
 
 
+def test_frame_batched_translator_equals_the_per_frame_passes():
+    """Frame-major batches run as ONE batch with a per-frame first-layer bias (mlp_engine: segmented bias; Deformer.BATCH_FRAMES) or as one
+    MLP pass per frame: same offsets, same first-order gradients (points, codes, every layer) and same SECOND-order gradients (the
+    group-2 double backward of the engine with a segmented bias), for a vertex count that is not a multiple of any tile size."""
+    from selfreconcode_amd.model import Deformer as D
+    tr = D.MLPTranslator(128, 6).to(DEV)
+    tr.load_state_dict(fx.det_params(fx.DEF_SPEC, 11), strict=True)
+    N, V = 3, 333
+    ps0 = fx.det_tensor((N, V, 3), 21, 0.7).to(DEV); conds0 = fx.det_tensor((N, 128), 22, 0.1).to(DEV)
+    cd, cg = fx.det_tensor((N, V, 3), 23, 1.0).to(DEV), fx.det_tensor((N, V, 3), 24, 1.0).to(DEV)
+    params = [tr.lin0.weight, tr.lin0.bias, tr.lin1.weight, tr.lin3.bias, tr.lin4.weight]
+
+    def run(batched):
+        old = D.BATCH_FRAMES
+        D.BATCH_FRAMES = batched
+        try:
+            ps = ps0.clone().requires_grad_(True); conds = conds0.clone().requires_grad_(True)
+            out = tr(ps, conds, ratio=RATIO)
+            first = torch.autograd.grad((out * cd).sum(), [ps, conds] + params, retain_graph=True)
+            gp = torch.autograd.grad(out, ps, cd, create_graph=True)[0]                       # d <out, cd> / d ps, kept differentiable
+            second = torch.autograd.grad((gp * cg).sum(), [ps, conds] + params, allow_unused=True)
+            dJ = D.translator_value_jacobian(tr, ps, conds, None, RATIO)
+            jac = torch.autograd.grad((dJ[0] * cd).sum() + (dJ[1].reshape(N, V, 9)[..., :3] * cg).sum(), [ps, conds] + params)
+            return out, first, second, dJ, jac
+        finally:
+            D.BATCH_FRAMES = old
+    a, b = run(True), run(False)
+    close(a[0], b[0], 1e-5, 1e-6)
+    close(a[3][0], b[3][0], 1e-5, 1e-6); close(a[3][1], b[3][1], 1e-5, 1e-6)
+    for which in (1, 2, 4):
+        for x, y in zip(a[which], b[which]):
+            assert (x is None) == (y is None)
+            if x is not None:
+                close(x, y, 1e-4, 1e-5 * max(1.0, float(y.abs().max())))
+
+
 def test_kinematic_chain_kernel_vs_oracle():
     """fused chain forward/backward (dual-number Rodrigues) == oracle lbs_transforms + autograd."""
     skin = _skinner()
