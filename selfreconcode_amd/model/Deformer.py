@@ -530,15 +530,22 @@ class TranslatorValueJacobian(torch.autograd.Function):
         WTs = [me.transposed_of(Ws[l], spec.layers[l].K) for l in range(nl)]
         acts_full = acts + [None]
         need_par = any(ctx.needs_input_grad[7:])
-        A0bar, dWs, dbs = me.reverse(spec, A0, WTs, acts_full, ybar.view(P * 4, 4), 4, True, need_par, Ws, list(wb[nl:]))
+        # the input cotangent (first-layer backward-data GEMM + the encoding's backward) only when somebody asks for it: the points
+        # or, through the code columns of the first layer's input, the per-frame codes (the regulariser's sample points need neither)
+        need_x = ctx.needs_input_grad[2]
+        need_in = need_x or (ctx.needs_input_grad[3] and ctx.E > 0)
+        A0bar, dWs, dbs = me.reverse(spec, A0, WTs, acts_full, ybar.view(P * 4, 4), 4, need_in, need_par, Ws, list(wb[nl:]))
         if not need_par:
             dWs, dbs = [None] * nl, [None] * nl
-        xbar = torch.empty_like(flat)
-        with torch.cuda.device(flat.device):
-            _lib.call("sr_pe_embed_bwd", _lib.ptr(flat), P, tr.multires, _lib.ptr(ctx.wt), 4, _lib.ptr(A0bar), A0bar.stride(0),
-                      _lib.ptr(xbar), _lib.stream_of(flat))
-        if dbar is not None:
-            xbar = xbar + dbar.reshape(-1, 3)
+        xbar = None
+        if need_x:
+            xbar = torch.empty_like(flat)
+            with torch.cuda.device(flat.device):
+                _lib.call("sr_pe_embed_bwd", _lib.ptr(flat), P, tr.multires, _lib.ptr(ctx.wt), 4, _lib.ptr(A0bar), A0bar.stride(0),
+                          _lib.ptr(xbar), _lib.stream_of(flat))
+            if dbar is not None:
+                xbar = xbar + dbar.reshape(-1, 3)
+            xbar = xbar.view(ctx.xshape)
         gcond = None
         if ctx.needs_input_grad[3] and ctx.E:
             E = ctx.E
@@ -548,7 +555,7 @@ class TranslatorValueJacobian(torch.autograd.Function):
             else:
                 gcond = (me.rows_frame_sum(ge, index, ctx.n_extra) if ctx.n_extra <= 32       # deterministic (index_add: float atomics)
                          else torch.zeros((ctx.n_extra, E), dtype=ge.dtype, device=ge.device).index_add(0, index, ge))
-        return (None, None, xbar.view(ctx.xshape), gcond, None, None, None) + tuple(dWs) + tuple(dbs)
+        return (None, None, xbar, gcond, None, None, None) + tuple(dWs) + tuple(dbs)
 
 
 def translator_value_jacobian(tr, ps, conds, batch_inds, ratio):

@@ -762,10 +762,13 @@ class OptimNetwork(nn.Module):
             # mean |f(v)| over ALL V vertices is the same on every rank and its gradient reaches only SDF parameters, which are
             # averaged over the ranks: rank r sums its vertices r::R and scales by R / V -- the rank mean of that is the full mean
             # (network.py:690-694), at 1/R of the SDF forward + backward per rank.  (`info` then holds this rank's estimate.)
-            mnfld_pred = self.sdf(self.TmpVs[rank::world], ratio, sdf_only=True).view(-1)
+            mnfld_pred = self.sdf(self.TmpVs.detach()[rank::world], ratio, sdf_only=True).view(-1)
             sdf_loss = (mnfld_pred + self.sdfShrinkRadius).abs().sum() * (float(world) / float(self.TmpVs.shape[0]))
         else:
-            mnfld_pred = self.sdf(self.TmpVs, ratio, sdf_only=True).view(-1)
+            # (detached: the reference lets the outer backward deposit d/dTmpVs of this term in TmpVs.grad, but nothing reads it -- the
+            # template's optimizer zeroes the gradient before its own inner backward, network.py:685-688 -- so the input-gradient GEMM of
+            # the first layer and the encoding's backward over all V vertices are skipped; every parameter gradient is unchanged)
+            mnfld_pred = self.sdf(self.TmpVs.detach(), ratio, sdf_only=True).view(-1)
             sdf_loss = (mnfld_pred + self.sdfShrinkRadius).abs().mean()
         self.info['pc_loss_sdf'] = sdf_loss.detach()
         return sdf_loss * (self.conf.get_float('pc_weight.weight') if 'pc_weight' in self.conf else 60.)
