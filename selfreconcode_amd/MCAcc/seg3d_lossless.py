@@ -97,7 +97,7 @@ class Seg3dLossless(nn.Module):
                 occ, bflag = interp2x_boundary3d.forward(occ.float().contiguous(), bal)
                 cand = torch.empty(D * H * W, dtype=torch.int64, device=dev)
                 cnt = torch.empty(1, dtype=torch.int64, device=dev)
-                with torch.cuda.device(dev):
+                with _lib.on_device(dev):
                     _lib.call("sr_seg3d_candidates", _lib.ptr(bflag), _lib.ptr(done), D, H, W, _lib.ptr(cand), _lib.ptr(cnt), _lib.stream_of(occ))
                 idx = cand[:int(cnt)].sort().values                             # (one host sync, as nonzero; sorted = the reference's order)
             else:

@@ -26,7 +26,7 @@ def Fast3x3Minv(ms):
     n = ms.size(0)
     invs = torch.empty((n, 3, 3), dtype=ms.dtype, device=ms.device)
     checks = torch.empty((n,), dtype=torch.bool, device=ms.device)
-    with torch.cuda.device(ms.device):
+    with _lib.on_device(ms.device):
         _lib.call("sr_minv3x3_fwd_" + _SUFFIX[ms.dtype], _lib.ptr(ms), _lib.ptr(invs), _lib.ptr(checks), n, _lib.stream_of(ms))
     return [invs, checks]
 
@@ -42,6 +42,6 @@ def Fast3x3Minv_backward(grads, invs):
         raise RuntimeError("invs must have same type with grads")
     n = invs.size(0)
     outs = torch.empty((n, 3, 3), dtype=invs.dtype, device=invs.device)
-    with torch.cuda.device(invs.device):
+    with _lib.on_device(invs.device):
         _lib.call("sr_minv3x3_bwd_" + _SUFFIX[invs.dtype], _lib.ptr(grads), _lib.ptr(invs), _lib.ptr(outs), n, _lib.stream_of(invs))
     return outs

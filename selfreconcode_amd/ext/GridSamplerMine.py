@@ -46,7 +46,7 @@ def forward(input, grid, interpolation_mode=0, padding_mode=1):
     _check(input, grid, interpolation_mode, padding_mode)
     N, C = input.shape[:2]
     out = torch.empty((N, C) + tuple(grid.shape[1:4]), dtype=input.dtype, device=input.device)
-    with torch.cuda.device(input.device):
+    with _lib.on_device(input.device):
         _lib.call("sr_gridsample3d_fwd_" + _SUFFIX[input.dtype], _lib.ptr(input), _lib.desc5(input), _lib.ptr(grid), _lib.desc5(grid),
                   _lib.ptr(out), _lib.desc5(out), _lib.stream_of(input))
     return out
@@ -57,7 +57,7 @@ def backward(input, grid, grad_output, interpolation_mode=0, padding_mode=1, wan
     grad_input = torch.zeros_like(input, memory_format=torch.contiguous_format) if want_grad_input else None
     grad_grid = torch.empty(tuple(grid.shape), dtype=grid.dtype, device=grid.device)
     gi_desc = _lib.desc5(grad_input) if want_grad_input else _lib.desc5(input)
-    with torch.cuda.device(input.device):
+    with _lib.on_device(input.device):
         _lib.call("sr_gridsample3d_bwd_" + _SUFFIX[input.dtype], _lib.ptr(input), _lib.desc5(input), _lib.ptr(grid), _lib.desc5(grid),
                   _lib.ptr(grad_output), _lib.desc5(grad_output), _lib.ptr(grad_input), gi_desc, _lib.ptr(grad_grid),
                   _lib.stream_of(input))
@@ -73,7 +73,7 @@ def dbackward(grad_output_input, grad_output_grid, input, grid, grad_output, int
     ggo = torch.empty((N, C) + tuple(grid.shape[1:4]), dtype=input.dtype, device=input.device)
     gi_desc = _lib.desc5(grad_input) if want_grad_input else _lib.desc5(input)
     goi_desc = _lib.desc5(grad_output_input) if grad_output_input is not None else _lib.desc5(input)
-    with torch.cuda.device(input.device):
+    with _lib.on_device(input.device):
         _lib.call("sr_gridsample3d_dbwd_" + _SUFFIX[input.dtype], _lib.ptr(grad_output_input), goi_desc,
                   _lib.ptr(grad_output_grid), _lib.desc5(grad_output_grid), _lib.ptr(input), _lib.desc5(input),
                   _lib.ptr(grid), _lib.desc5(grid), _lib.ptr(grad_output), _lib.desc5(grad_output),

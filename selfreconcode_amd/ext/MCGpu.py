@@ -28,7 +28,7 @@ def mc_gpu(sdfs, xstep=1.0, ystep=1.0, zstep=1.0, xmin=0.0, ymin=0.0, zmin=0.0, 
     if nx <= 0 or ny <= 0 or nz <= 0:
         return []
     dev = sdfs.device
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         st = _lib.stream_of(sdfs)
         nbytes = _lib.raw("sr_mc_workspace_bytes")(nx, ny, nz)
         ws = torch.empty((nbytes // 4,), dtype=torch.int32, device=dev)

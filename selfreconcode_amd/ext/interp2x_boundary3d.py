@@ -22,7 +22,7 @@ def forward(input, balance_value):
     B, C, d, h, w = input.shape
     out = torch.empty((B, C, 2 * d - 1, 2 * h - 1, 2 * w - 1), dtype=input.dtype, device=input.device)
     bnd = torch.empty(out.shape, dtype=torch.bool, device=input.device)
-    with torch.cuda.device(input.device):
+    with _lib.on_device(input.device):
         _lib.call("sr_interp2x3d_fwd_" + _SUFFIX[input.dtype], _lib.ptr(input), B * C, d, h, w, float(balance_value), _lib.ptr(out),
                   _lib.ptr(bnd), _lib.stream_of(input))
     return [out, bnd]
@@ -33,6 +33,6 @@ def backward(grad_output):
     B, C, D, H, W = grad_output.shape
     d, h, w = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
     gi = torch.empty((B, C, d, h, w), dtype=grad_output.dtype, device=grad_output.device)
-    with torch.cuda.device(grad_output.device):
+    with _lib.on_device(grad_output.device):
         _lib.call("sr_interp2x3d_bwd_" + _SUFFIX[grad_output.dtype], _lib.ptr(grad_output), B * C, d, h, w, _lib.ptr(gi), _lib.stream_of(grad_output))
     return gi

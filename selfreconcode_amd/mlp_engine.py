@@ -171,7 +171,7 @@ def split_bf16x3(M, K):
     rows = M.shape[0]
     ld3 = (K + 15) // 16 * 16
     out = torch.empty((3, rows, ld3), dtype=torch.int16, device=M.device)
-    with torch.cuda.device(M.device):
+    with _lib.on_device(M.device):
         _lib.call("sr_split_bf16x3", _lib.ptr(M), M.stride(0), rows, K, _lib.ptr(out), ld3, rows * ld3, _lib.stream_of(M))
     return out, ld3
 
@@ -260,7 +260,7 @@ def forward(spec, A0, Ws, bs, group):
     R = A0.shape[0]
     acts, X = [], A0
     seg = _bias_segments(bs[0], R, group)
-    with torch.cuda.device(A0.device):
+    with _lib.on_device(A0.device):
         for l, L in enumerate(spec.layers):
             _check_mat(Ws[l], f"W{l}")
             C = torch.empty((R, pad4(L.N + L.nfill)), dtype=torch.float32, device=A0.device)
@@ -343,7 +343,7 @@ def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_g
     Zbar = Ybar
     A0bar = None
     seg = _bias_segments(bs[0], R, group) if bs is not None else None
-    with torch.cuda.device(A0.device):
+    with _lib.on_device(A0.device):
         for l in range(nl - 1, -1, -1):
             L = spec.layers[l]
             X = A0 if l == 0 else acts[l - 1]
@@ -427,7 +427,7 @@ def rows_pad(a, width, b=None, pair=False):
         srcs.append(t)
     a, b = srcs
     out = torch.empty((R * (2 if pair else 1), width), dtype=torch.float32, device=ref.device)
-    with torch.cuda.device(ref.device):
+    with _lib.on_device(ref.device):
         _lib.call("sr_rows_pad", _lib.ptr(a), 0 if a is None else a.stride(0), 0 if a is None else min(a.shape[1], width),
                   _lib.ptr(b), 0 if b is None else b.stride(0), 0 if b is None else min(b.shape[1], width),
                   R, 2 if pair else 1, _lib.ptr(out), width, width, _lib.stream_of(ref))
@@ -443,7 +443,7 @@ def rows_frame_sum(X, index, n):
     index = index.contiguous()
     out = torch.empty((n, E), dtype=torch.float32, device=X.device)
     part = torch.empty((max(int(_lib.raw("sr_rows_frame_sum_workspace_floats")(P, E, n)), 1),), dtype=torch.float32, device=X.device)
-    with torch.cuda.device(X.device):
+    with _lib.on_device(X.device):
         _lib.call("sr_rows_frame_sum", _lib.ptr(X), X.stride(0), P, E, _lib.ptr(index), n, _lib.ptr(part), _lib.ptr(out), _lib.stream_of(X))
     return out
 
@@ -683,7 +683,7 @@ def refresh_packs(lins):
             L.v, L.g = _lib.ptr(vv), (0 if g is None else _lib.ptr(g.detach().contiguous()))
             L.W, L.WT, L.norms = _lib.ptr(e["W"]), _lib.ptr(e["WT"]), (0 if g is None else _lib.ptr(e["norms"]))
             L.N, L.K, L.ldw, L.ldwt = v.shape[0], v.shape[1], e["W"].stride(0), e["WT"].stride(0)
-        with torch.cuda.device(chunk[0][1].device), torch.no_grad():
+        with _lib.on_device(chunk[0][1].device), torch.no_grad():
             _lib.call("sr_pack_weights", ctypes.byref(t), _lib.stream_of(chunk[0][1]))
         for e, v, g, sig in chunk:
             e["sig"] = sig
@@ -823,7 +823,7 @@ def flush_param_grads(only=None):
             L.db, L.gb = (_lib.ptr(e["db"]), _lib.ptr(b.grad)) if fold_bias else (0, 0)
             outs.append((e, v, g, gv, gg, acc, vd, fold_bias))
         dev = chunk[0]["W"].device
-        with torch.cuda.device(dev), torch.no_grad():
+        with _lib.on_device(dev), torch.no_grad():
             _lib.call("sr_unpack_grads", ctypes.byref(t), torch.cuda.current_stream(dev).cuda_stream)
         for e, v, g, gv, gg, acc, _, fold_bias in outs:
             if acc:

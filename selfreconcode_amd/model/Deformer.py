@@ -287,7 +287,7 @@ class LBSkinner(nn.Module):
         for i in range(3):
             a.bmin[i], a.bmax[i] = box[0][i], box[1][i]
         a.y, a.jac = _lib.ptr(y), _lib.ptr(jac)
-        with torch.cuda.device(flat.device):
+        with _lib.on_device(flat.device):
             _lib.call("sr_lbs_fwd", ctypes.byref(a), _lib.stream_of(flat))
         return y.view(ps.shape), jac
 
@@ -344,7 +344,7 @@ class LBSkinner(nn.Module):
         Abar = torch.empty((A.shape[0], 24, 12), device=flat.device) if need_A else None            # written, not accumulated
         tbar = torch.empty((A.shape[0], 3), device=flat.device) if need_t else None
         part = torch.empty((max(int(_lib.raw("sr_lbs_bwd_workspace_floats")(P, A.shape[0])), 1),), device=flat.device)
-        with torch.cuda.device(flat.device):
+        with _lib.on_device(flat.device):
             _lib.call("sr_lbs_bwd", ctypes.byref(a), _lib.ptr(yb), _lib.ptr(pbar), _lib.ptr(Abar), _lib.ptr(tbar), _lib.ptr(part), _lib.stream_of(flat))
         return pbar, Abar, tbar
 
@@ -357,7 +357,7 @@ class _PosedChain(torch.autograd.Function):
         G = torch.empty((B, 24, 4, 4), dtype=torch.float32, device=p.device)
         A = torch.empty_like(G)
         js, pa, ip = skin._host_consts()
-        with torch.cuda.device(p.device):
+        with _lib.on_device(p.device):
             _lib.call("sr_lbs_chain_fwd", _lib.ptr(p), B, js, pa, ip, _lib.ptr(G), _lib.ptr(A), _lib.stream_of(p))
         ctx.skin = skin
         ctx.save_for_backward(p)
@@ -374,7 +374,7 @@ class _PosedChain(torch.autograd.Function):
         out = torch.empty_like(p)
         gb = None if Gbar is None else Gbar.contiguous().float()
         ab = None if Abar is None else Abar.contiguous().float()
-        with torch.cuda.device(p.device):
+        with _lib.on_device(p.device):
             _lib.call("sr_lbs_chain_bwd", _lib.ptr(p), p.shape[0], js, pa, ip, _lib.ptr(ab), _lib.ptr(gb), _lib.ptr(out), _lib.stream_of(p))
         return None, out.view(ctx.pshape)
 
@@ -447,7 +447,7 @@ class _LBSValueJacobian(torch.autograd.Function):
         Abar = torch.empty((A.shape[0], 24, 12), device=flat.device) if need_A else None            # written, not accumulated
         tbar = torch.empty((A.shape[0], 3), device=flat.device) if (need_t and yb is not None) else None
         part = torch.empty((max(int(_lib.raw("sr_lbs_bwd_workspace_floats")(P, A.shape[0])), 1),), device=flat.device)
-        with torch.cuda.device(flat.device):
+        with _lib.on_device(flat.device):
             _lib.call("sr_lbs_jac_bwd", ctypes.byref(a), _lib.ptr(yb), _lib.ptr(Jb), _lib.ptr(qbar), _lib.ptr(Abar), _lib.ptr(tbar), _lib.ptr(part),
                       _lib.stream_of(flat))
         if Abar is not None:
@@ -498,7 +498,7 @@ class TranslatorValueJacobian(torch.autograd.Function):
         ldo = me.pad4(3 + 6 * tr.multires + E)
         A0 = torch.empty((P * 4, ldo), dtype=torch.float32, device=flat.device)
         cd = None if conds is None else conds.reshape(-1, E).contiguous().float()
-        with torch.cuda.device(flat.device):
+        with _lib.on_device(flat.device):
             _lib.call("sr_pe_embed", _lib.ptr(flat), P, tr.multires, _lib.ptr(wt), _lib.ptr(cd), 0 if cd is None else cd.stride(0), E,
                       _lib.ptr(index), 4, _lib.ptr(A0), ldo, _lib.stream_of(flat))
             acts = me.forward(spec, A0, Ws, bs, 4)
@@ -540,7 +540,7 @@ class TranslatorValueJacobian(torch.autograd.Function):
         xbar = None
         if need_x:
             xbar = torch.empty_like(flat)
-            with torch.cuda.device(flat.device):
+            with _lib.on_device(flat.device):
                 _lib.call("sr_pe_embed_bwd", _lib.ptr(flat), P, tr.multires, _lib.ptr(ctx.wt), 4, _lib.ptr(A0bar), A0bar.stride(0),
                           _lib.ptr(xbar), _lib.stream_of(flat))
             if dbar is not None:

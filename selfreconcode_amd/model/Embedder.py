@@ -46,7 +46,7 @@ class PEFunction(torch.autograd.Function):
         ldo = pad4(3 + 6 * L + E)
         out = torch.empty((P, ldo), dtype=torch.float32, device=x.device)
         ex = None if extra is None else extra.contiguous().float()
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.call("sr_pe_embed", _lib.ptr(x), P, L, _lib.ptr(wt), _lib.ptr(ex), 0 if ex is None else ex.stride(0), E,
                       _lib.ptr(extra_index), 1, _lib.ptr(out), ldo, _lib.stream_of(x))
         ctx.L, ctx.E, ctx.segment = L, E, segment
@@ -65,7 +65,7 @@ class PEFunction(torch.autograd.Function):
             # create_graph=True, where the backward itself must be differentiable)
             g = g.contiguous()
             gx = torch.empty_like(x)
-            with torch.cuda.device(x.device):
+            with _lib.on_device(x.device):
                 _lib.call("sr_pe_embed_bwd", _lib.ptr(x), P, L, _lib.ptr(ctx.wt), 1, _lib.ptr(g), g.stride(0), _lib.ptr(gx), _lib.stream_of(x))
         elif not ctx.needs_input_grad[0]:
             gx = None

@@ -15,7 +15,7 @@ class SingularValues3x3(Function):
         n = A.shape[0]
         U = torch.empty_like(A); V = torch.empty_like(A)
         S = torch.empty((n, 3), dtype=torch.float32, device=A.device)
-        with torch.cuda.device(A.device):
+        with _lib.on_device(A.device):
             _lib.call("sr_svd3x3", _lib.ptr(A), n, _lib.ptr(U), _lib.ptr(S), _lib.ptr(V), _lib.stream_of(A))
         ctx.save_for_backward(U, V)
         return S
@@ -46,7 +46,7 @@ class PointsSilhouette(Function):
         ws = torch.empty((max(int(nbytes), 256) + 255,), dtype=torch.uint8, device=xy.device)
         off = (-ws.data_ptr()) % 256
         mask = torch.empty((N, H, W), dtype=torch.float32, device=xy.device)
-        with torch.cuda.device(xy.device):
+        with _lib.on_device(xy.device):
             _lib.call("sr_points_silhouette_fwd", _lib.ptr(xy), _lib.ptr(zz), N, V, H, W, float(radius), int(K), _lib.ptr(mask),
                       ws.data_ptr() + off, _lib.stream_of(xy))
         ctx.save_for_backward(xy, zz, ws)
@@ -58,7 +58,7 @@ class PointsSilhouette(Function):
         xy, zz, ws = ctx.saved_tensors
         H, W, radius, off = ctx.dims
         gxy = torch.empty_like(xy)
-        with torch.cuda.device(xy.device):
+        with _lib.on_device(xy.device):
             _lib.call("sr_points_silhouette_bwd", _lib.ptr(xy), _lib.ptr(zz), xy.shape[0], xy.shape[1], H, W, radius, ws.data_ptr() + off,
                       _lib.ptr(gmask.contiguous().float()), _lib.ptr(gxy), _lib.stream_of(xy))
         return gxy, None, None, None, None, None
@@ -96,7 +96,7 @@ def rasterize_meshes(xy_ndc, z, faces, H, W):
     p2f = torch.empty((N, H, W), dtype=torch.int64, device=dev)
     bary = torch.empty((N, H, W, 3), dtype=torch.float32, device=dev)
     zo = torch.empty((N, H, W), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.call("sr_rasterize_meshes", _lib.ptr(xy), _lib.ptr(z), _lib.ptr(faces), N, V, faces.shape[0], H, W, _lib.ptr(zbuf), _lib.ptr(p2f),
                   _lib.ptr(bary), _lib.ptr(zo), _lib.stream_of(xy))
     return Fragments(p2f.unsqueeze(-1), bary.unsqueeze(3), zo.unsqueeze(-1))

@@ -77,7 +77,7 @@ class FusedAdam(torch.optim.Optimizer):
             if c is None:
                 c = corr[k] = (1.0 - b1 ** k, 1.0 / math.sqrt(1.0 - b2 ** k))
             T.g, T.lr, T.bias1, T.inv_sqrt_bias2 = g.data_ptr(), group['lr'], c[0], c[1]
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             for t in cache[1]:
                 _lib.call("sr_adam_step", ctypes.byref(t), stream)

@@ -84,7 +84,7 @@ class ProjectNDC(Function):
         cam = _CamArgs(R, T, f, c, W, H)
         xy = torch.empty((n, 2), dtype=torch.float32, device=p.device)
         z = torch.empty((n,), dtype=torch.float32, device=p.device)
-        with torch.cuda.device(p.device):
+        with _lib.on_device(p.device):
             _lib.call("sr_cam_project_ndc_fwd", _lib.ptr(p), n, cam.ref(), _lib.ptr(xy), _lib.ptr(z), _lib.stream_of(p))
         ctx.save_for_backward(p, R, T, f, c)
         ctx.WH, ctx.pshape = (W, H), ps.shape
@@ -107,7 +107,7 @@ class ProjectNDC(Function):
             partial = torch.empty((max(_lib.raw("sr_step_param_blocks")(n), 1), 16), dtype=torch.float32, device=p.device)
         gxy_c = None if gxy is None else _f32c(gxy).view(-1, 2)
         gz_c = None if gz is None else _f32c(gz).view(-1)
-        with torch.cuda.device(p.device):
+        with _lib.on_device(p.device):
             _lib.call("sr_cam_project_ndc_bwd", _lib.ptr(p), n, cam.ref(), _lib.ptr(gxy_c), _lib.ptr(gz_c), _lib.ptr(gps), _lib.ptr(partial),
                       _lib.ptr(gparams), _lib.stream_of(p))
         gR = gT = gf = gc = None
@@ -126,7 +126,7 @@ class ViewRays(Function):
         n = px.shape[0]
         cam = _CamArgs(R, None, f, c, 2., 2.)
         rays = torch.empty((n, 3), dtype=torch.float32, device=px.device)
-        with torch.cuda.device(px.device):
+        with _lib.on_device(px.device):
             _lib.call("sr_cam_view_rays_fwd", _lib.ptr(px), n, cam.ref(), _lib.ptr(rays), _lib.stream_of(px))
         ctx.save_for_backward(px, R, f, c)
         ctx.set_materialize_grads(False)
@@ -141,7 +141,7 @@ class ViewRays(Function):
         cam = _CamArgs(R, None, f, c, 2., 2.)
         gparams = torch.empty((16,), dtype=torch.float32, device=px.device)
         partial = torch.empty((max(_lib.raw("sr_step_param_blocks")(n), 1), 16), dtype=torch.float32, device=px.device)
-        with torch.cuda.device(px.device):
+        with _lib.on_device(px.device):
             _lib.call("sr_cam_view_rays_bwd", _lib.ptr(px), n, cam.ref(), _lib.ptr(_f32c(grays)), _lib.ptr(partial), _lib.ptr(gparams),
                       _lib.stream_of(px))
         needs = (ctx.needs_input_grad[1], False, ctx.needs_input_grad[2], ctx.needs_input_grad[3])
@@ -160,7 +160,7 @@ class CardinalRays(Function):
         n = Jc.shape[0]
         out = torch.empty((n, 3), dtype=torch.float32, device=Jc.device)
         ok = torch.empty((n,), dtype=torch.bool, device=Jc.device)
-        with torch.cuda.device(Jc.device):
+        with _lib.on_device(Jc.device):
             _lib.call("sr_cardinal_rays_fwd", _lib.ptr(Jc), _lib.ptr(vc), n, _lib.ptr(out), _lib.ptr(ok), _lib.stream_of(Jc))
         ctx.save_for_backward(Jc, vc)
         ctx.mark_non_differentiable(ok)
@@ -177,7 +177,7 @@ class CardinalRays(Function):
         gv = torch.empty_like(vc) if ctx.needs_input_grad[1] else None
         if gJ is None and gv is None:
             return None, None
-        with torch.cuda.device(Jc.device):
+        with _lib.on_device(Jc.device):
             _lib.call("sr_cardinal_rays_bwd", _lib.ptr(Jc), _lib.ptr(vc), n, _lib.ptr(_f32c(gout)), _lib.ptr(gJ), _lib.ptr(gv), _lib.stream_of(Jc))
         return gJ, gv
 
@@ -187,7 +187,7 @@ def deformed_normals(J, onx):
     _lib.require_gpu(J, onx)
     Jc, oc = _f32c(J).view(-1, 3, 3), _f32c(onx).view(-1, 3)
     out = torch.empty_like(oc)
-    with torch.cuda.device(Jc.device):
+    with _lib.on_device(Jc.device):
         _lib.call("sr_deformed_normals", _lib.ptr(Jc), _lib.ptr(oc), Jc.shape[0], _lib.ptr(out), _lib.stream_of(Jc))
     return out
 
@@ -211,7 +211,7 @@ class ColorLoss(Function):
         N, H, W = g.shape[0], g.shape[1], g.shape[2]
         px, keep = _pixels(b, r, c, N, H, W)
         out, partial = _loss_buffers(px.P, col.device)
-        with torch.cuda.device(col.device):
+        with _lib.on_device(col.device):
             _lib.call("sr_color_loss_fwd", ctypes.byref(px), _lib.ptr(col), _lib.ptr(g), _lib.ptr(partial), _lib.ptr(out), _lib.stream_of(col))
         ctx.save_for_backward(col, g, out, *keep)
         ctx.dims = (N, H, W)
@@ -222,7 +222,7 @@ class ColorLoss(Function):
         col, g, out, b, r, c = ctx.saved_tensors
         px, _ = _pixels(b, r, c, *ctx.dims)
         gcol = torch.empty_like(col)
-        with torch.cuda.device(col.device):
+        with _lib.on_device(col.device):
             _lib.call("sr_color_loss_bwd", ctypes.byref(px), _lib.ptr(col), _lib.ptr(g), _lib.ptr(out), _lib.ptr(_gscalar(gloss)), _lib.ptr(gcol),
                       _lib.stream_of(col))
         return gcol, None, None, None, None
@@ -239,7 +239,7 @@ class NormalLoss(Function):
         N, H, W = g.shape[0], g.shape[1], g.shape[2]
         px, keep = _pixels(b, r, c, N, H, W)
         out, partial = _loss_buffers(px.P, nx.device)
-        with torch.cuda.device(nx.device):
+        with _lib.on_device(nx.device):
             _lib.call("sr_normal_loss_fwd", ctypes.byref(px), _lib.ptr(nx), _lib.ptr(Jc), _lib.ptr(g), _lib.ptr(Rc), _lib.ptr(rc), 1 if weighted else 0,
                       _lib.ptr(partial), _lib.ptr(out), _lib.stream_of(nx))
         ctx.save_for_backward(nx, Jc, g, Rc, out, *keep, *(() if rc is None else (rc,)))
@@ -254,7 +254,7 @@ class NormalLoss(Function):
         px, _ = _pixels(b, r, c, *ctx.dims)
         gnx = torch.empty_like(nx)
         gJ = torch.empty_like(Jc) if ctx.needs_input_grad[1] else None
-        with torch.cuda.device(nx.device):
+        with _lib.on_device(nx.device):
             _lib.call("sr_normal_loss_bwd", ctypes.byref(px), _lib.ptr(nx), _lib.ptr(Jc), _lib.ptr(g), _lib.ptr(Rc), _lib.ptr(rc), 1 if ctx.weighted else 0,
                       _lib.ptr(out), _lib.ptr(_gscalar(gloss)), _lib.ptr(gnx), _lib.ptr(gJ), _lib.stream_of(nx))
         return gnx, gJ, None, None, None, None, None, None, None
@@ -268,7 +268,7 @@ class EikonalLoss(Function):
         _lib.require_gpu(g)
         gc = _f32c(g).view(-1, 3)
         out, partial = _loss_buffers(gc.shape[0], gc.device)
-        with torch.cuda.device(gc.device):
+        with _lib.on_device(gc.device):
             _lib.call("sr_eikonal_loss_fwd", _lib.ptr(gc), gc.shape[0], _lib.ptr(partial), _lib.ptr(out), _lib.stream_of(gc))
         ctx.save_for_backward(gc)
         ctx.shape = g.shape
@@ -278,7 +278,7 @@ class EikonalLoss(Function):
     def backward(ctx, gloss):
         gc, = ctx.saved_tensors
         gg = torch.empty_like(gc)
-        with torch.cuda.device(gc.device):
+        with _lib.on_device(gc.device):
             _lib.call("sr_eikonal_loss_bwd", _lib.ptr(gc), gc.shape[0], _lib.ptr(_gscalar(gloss)), _lib.ptr(gg), _lib.stream_of(gc))
         return gg.view(ctx.shape)
 
@@ -294,7 +294,7 @@ class DefReguLoss(Function):
         U = torch.empty_like(A); V = torch.empty_like(A)
         S = torch.empty((n, 3), dtype=torch.float32, device=A.device)
         out, partial = _loss_buffers(n, A.device)
-        with torch.cuda.device(A.device):
+        with _lib.on_device(A.device):
             st = _lib.stream_of(A)
             _lib.call("sr_svd3x3", _lib.ptr(A), n, _lib.ptr(U), _lib.ptr(S), _lib.ptr(V), st)
             _lib.call("sr_def_regu_loss_fwd", _lib.ptr(S), n, float(c), _lib.ptr(partial), _lib.ptr(out), st)
@@ -306,7 +306,7 @@ class DefReguLoss(Function):
     def backward(ctx, gloss):
         U, S, V = ctx.saved_tensors
         gJ = torch.empty_like(U)
-        with torch.cuda.device(U.device):
+        with _lib.on_device(U.device):
             _lib.call("sr_def_regu_loss_bwd", _lib.ptr(U), _lib.ptr(S), _lib.ptr(V), U.shape[0], ctx.c, _lib.ptr(_gscalar(gloss)), _lib.ptr(gJ),
                       _lib.stream_of(U))
         return gJ.view(ctx.shape), None
@@ -322,7 +322,7 @@ class MaskIoULoss(Function):
         N = m.shape[0]
         hw = m.numel() // N
         out, partial = _loss_buffers(m.numel(), m.device)
-        with torch.cuda.device(m.device):
+        with _lib.on_device(m.device):
             _lib.call("sr_mask_iou_loss_fwd", _lib.ptr(m), _lib.ptr(g), N, hw, _lib.ptr(partial), _lib.ptr(out), _lib.stream_of(m))
         ctx.save_for_backward(m, g, out)
         return out[0]
@@ -332,7 +332,7 @@ class MaskIoULoss(Function):
         m, g, out = ctx.saved_tensors
         N = m.shape[0]
         gm = torch.empty_like(m)
-        with torch.cuda.device(m.device):
+        with _lib.on_device(m.device):
             _lib.call("sr_mask_iou_loss_bwd", _lib.ptr(m), _lib.ptr(g), N, m.numel() // N, _lib.ptr(out), _lib.ptr(_gscalar(gloss)), _lib.ptr(gm),
                       _lib.stream_of(m))
         return gm, None
@@ -349,7 +349,7 @@ def implicit_solve(grad_f, J, v, grad_l):
     tail = torch.empty((n, 3), dtype=torch.float32, device=dev)
     temp = torch.empty((n, 3), dtype=torch.float32, device=dev)
     ok = torch.empty((n,), dtype=torch.bool, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.call("sr_implicit_solve", _lib.ptr(gf), _lib.ptr(Jc), _lib.ptr(vc), _lib.ptr(gl), n, _lib.ptr(cot_f), _lib.ptr(tail), _lib.ptr(temp),
                   _lib.ptr(ok), _lib.stream_of(gf))
     return cot_f, tail, temp, ok

@@ -93,7 +93,7 @@ class _FusedEval:
 
     def evaluate(self, x, bi, group):
         """-> (sdf rows [M*group, ld], offset rows [M*group, ld], y [M,3], J_lbs [M,3,3] or None)"""
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             A0 = self._embed(x, self.sdf.multires, self.w_sdf, None, None, group)
             sdf_rows = me.forward(self.sdf_spec, A0, self.sdf_W, self.sdf_b, group)[-1]
             A0d = self._embed(x, self.tr.multires, self.w_def, self.conds, bi, group)
@@ -107,7 +107,7 @@ def _newton_reverse(ev, x, bi, rays, cam, dthr, athr, w1, w2, update):
     """One refiner step with reverse-mode derivatives (2x the rows of a value pass instead of 4x)."""
     M = x.shape[0]
     dev = x.device
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         A0 = ev._embed(x, ev.sdf.multires, ev.w_sdf, None, None, 1)
         acts = me.forward(ev.sdf_spec, A0, ev.sdf_W, ev.sdf_b, 1)
         A0d = ev._embed(x, ev.tr.multires, ev.w_def, ev.conds, bi, 1)
@@ -150,7 +150,7 @@ def _newton(ev, x, bi, rays, cam, group, dthr, athr, w1, w2, update):
     a.y, a.jlbs, a.rays, a.cam = _lib.ptr(y), _lib.ptr(jl), _lib.ptr(rays), _lib.ptr(cam)
     a.p, a.p_out, a.converged = _lib.ptr(x), _lib.ptr(xnew), _lib.ptr(conv)
     a.dthreshold, a.athreshold, a.w1, a.w2 = dthr, athr, w1, w2
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.call("sr_newton_update", ctypes.byref(a), _lib.stream_of(x))
     return xnew, conv
 
@@ -297,7 +297,7 @@ def _optimize_device_driven(ev, cam, rays, initTmpPs, batch_inds, dthreshold, at
     for c in (fwd, rev):
         c.m_mul, c.barrier, c.error, c.poll_mode = 1, ws.sync.data_ptr(), ws.sync.data_ptr() + 4, CHAIN_POLL_MODE
         c.m_cap, c.persistent = P, 1 if CHAIN_PERSISTENT else 0
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         st = _lib.stream_of(x0)
         ra = ctypes.byref(a)
         _lib.call("sr_refine_init", ra, st)

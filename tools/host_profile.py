@@ -9,11 +9,15 @@ from selfreconcode_amd.synthetic import build_synthetic_scene
 from selfreconcode_amd.optim import FusedAdam
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+FR = int(os.environ.get('SR_HP_FRAMES', '3'))                 # frames per step (1 + SR_HP_SIM_WORLD=8: the workload of one rank of configs[2])
+if int(os.environ.get('SR_HP_SIM_WORLD', '0')) > 1:
+    from selfreconcode_amd import dist as _srdist
+    _srdist.simulate_world((0, int(os.environ['SR_HP_SIM_WORLD'])))
 dev = torch.device('cuda:0')
 net, ds, conf = build_synthetic_scene(device=dev, frame_num=64, stage='coarse', consistent_masks=False)
 params = [p for p in net.parameters() if p.requires_grad]
 mlp_engine.set_deferred_param_grads(True)
-opt = FusedAdam([{'params': ds.learnable_weights()}, {'params': params}], lr=3.7e-6)
+opt = FusedAdam([{'params': ds.learnable_weights()}, {'params': params}], lr=float(os.environ.get('SR_HP_LR', '1e-4')))
 ratio = {'sdfRatio': 1., 'deformerRatio': 0.6, 'renderRatio': 1.}
 state = {'it': 0}
 marks = []
@@ -21,7 +25,7 @@ marks = []
 
 def step(mark=False):
     it = state['it']
-    f = torch.arange(3 * it % 60, 3 * it % 60 + 3, device=dev)
+    f = torch.arange(FR * it % 56, FR * it % 56 + FR, device=dev)
     t0 = time.perf_counter()
     opt.zero_grad(set_to_none=True)
     loss = net(ds.batch(f), 2048, ratio, f)
