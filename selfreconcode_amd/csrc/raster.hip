@@ -391,7 +391,41 @@ __global__ __launch_bounds__(256) void rm_pass1b(const float* __restrict__ xy, c
     if (!load_tri(xy, z, faces, img, V, f, t)) continue;
     const Box b = tri_box(t, H, W);
     const int bw = b.c1 - b.c0 + 1, npix = bw * (b.r1 - b.r0 + 1);
-    for (int p = lane; p < npix; p += 64) raster_pixel(t, b.c0 + p % bw, b.r0 + p / bw, img, f, H, W, zbuf);
+    if (fminf(t.z0, fminf(t.z1, t.z2)) <= 0.f) {
+      // a vertex behind the camera (unclipped, as pytorch3d 0.4.0): the pixels that pass face_hit are NOT the interior of the projected
+      // triangle then, so every pixel centre of the box is tested
+      for (int p = lane; p < npix; p += 64) raster_pixel(t, b.c0 + p % bw, b.r0 + p / bw, img, f, H, W, zbuf);
+      continue;
+    }
+    // All vertices in front: a pixel centre passes only strictly inside the projected triangle.  A lane takes a LINE of the box -- a row if
+    // the box is taller than wide, a column otherwise -- and walks the pixel centres between the two edge crossings of that line (+- one
+    // pixel of slack; raster_pixel repeats the exact test), so a long thin face -- the stretched faces of a template whose neighbouring
+    // vertices follow different bones have boxes of 10^3..10^5 pixel centres and cover a few hundred -- costs its lines + its area, not
+    // its box.
+    const bool by_rows = (b.r1 - b.r0) >= (b.c1 - b.c0);
+    const int l0 = by_rows ? b.r0 : b.c0, l1 = by_rows ? b.r1 : b.c1;          // the lines
+    const int m0 = by_rows ? b.c0 : b.r0, m1 = by_rows ? b.c1 : b.r1;          // the range along a line
+    const int nl = by_rows ? H : W, nm = by_rows ? W : H;
+    // u = the coordinate that is constant on a line, v = the one that runs along it
+    const float eu[3] = {by_rows ? t.y0 : t.x0, by_rows ? t.y1 : t.x1, by_rows ? t.y2 : t.x2};
+    const float ev[3] = {by_rows ? t.x0 : t.y0, by_rows ? t.x1 : t.y1, by_rows ? t.x2 : t.y2};
+    for (int l = l0 + lane; l <= l1; l += 64) {
+      const float uf = pix_to_ndc(l, nl);
+      float vlo = 3.0e38f, vhi = -3.0e38f;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const float ua = eu[e], va = ev[e], ub = eu[(e + 1) % 3], vb = ev[(e + 1) % 3];
+        if ((uf - ua) * (uf - ub) > 0.f) continue;                   // the line misses this edge
+        if (ua == ub) { vlo = fminf(vlo, fminf(va, vb)); vhi = fmaxf(vhi, fmaxf(va, vb)); continue; }
+        const float v = va + (uf - ua) * ((vb - va) / (ub - ua));
+        vlo = fminf(vlo, v); vhi = fmaxf(vhi, v);
+      }
+      if (vlo > vhi) continue;
+      // index of an NDC coordinate v along the line: ((1 - v) n - 1) / 2, decreasing in v
+      const int i0 = max(m0, (int)floorf(((1.0f - vhi) * (float)nm - 1.0f) * 0.5f) - 1);
+      const int i1 = min(m1, (int)ceilf(((1.0f - vlo) * (float)nm - 1.0f) * 0.5f) + 1);
+      for (int i2 = i0; i2 <= i1; ++i2) raster_pixel(t, by_rows ? i2 : l, by_rows ? l : i2, img, f, H, W, zbuf);
+    }
   }
 }
 

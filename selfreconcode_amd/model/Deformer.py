@@ -67,14 +67,8 @@ class MLPTranslator(nn.Module):
         self.offset = None
 
     def packed_weights(self):
-        from ..mlp_engine import refresh_packs
-        refresh_packs([getattr(self, "lin" + str(l)) for l in range(len(self.spec.layers))])
-        Ws, bs = [], []
-        for l, L in enumerate(self.spec.layers):
-            lin = getattr(self, "lin" + str(l))
-            Ws.append(pack_linear(lin))
-            bs.append(lin.bias)
-        return Ws, bs
+        from ..mlp_engine import packed_weights_of
+        return packed_weights_of(self, len(self.spec.layers))
 
     def hoisted_first_layer(self, conds):
         """The per-frame code enters the first layer only through W0[:, PE:] code_f -- a constant per frame.  For batches laid out

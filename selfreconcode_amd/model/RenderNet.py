@@ -5,7 +5,7 @@ import torch.nn as nn
 
 from .Embedder import embed_rows
 from .network import effective_weight
-from ..mlp_engine import MLPSpec, mlp_apply, pad_cols, pad4, pack_linear, refresh_packs
+from ..mlp_engine import MLPSpec, mlp_apply, pad_cols, pad4, pack_linear, refresh_packs, packed_weights_of
 from ..utils.utils import resolve_band_weights
 
 
@@ -35,9 +35,7 @@ class RenderingNetwork_view_norm(nn.Module):
         if pad4(width) != width:                  # the row pitch the GEMM wants, as a fifth block of the same cat (no separate pad pass)
             parts.append(points.new_zeros((points.shape[0], pad4(width) - width)))
         x = torch.cat(parts, dim=-1)
-        lins = [getattr(self, "lin" + str(l)) for l in range(len(self.spec.layers))]
-        refresh_packs(lins)                       # one launch for all stale layers after an optimizer step
-        Ws, bs = [pack_linear(lin) for lin in lins], [lin.bias for lin in lins]
+        Ws, bs = packed_weights_of(self, len(self.spec.layers))      # one launch for all stale layers after an optimizer step
         return torch.tanh(mlp_apply(self.spec, x, Ws, bs))
 
 

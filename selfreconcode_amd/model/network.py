@@ -62,14 +62,8 @@ class ImplicitNetwork(nn.Module):
         self.rendcond = None
 
     def packed_weights(self):
-        from ..mlp_engine import refresh_packs
-        refresh_packs([getattr(self, "lin" + str(l)) for l in range(len(self.spec.layers))])
-        Ws, bs = [], []
-        for l, L in enumerate(self.spec.layers):
-            lin = getattr(self, "lin" + str(l))
-            Ws.append(pack_linear(lin))
-            bs.append(lin.bias)
-        return Ws, bs
+        from ..mlp_engine import packed_weights_of
+        return packed_weights_of(self, len(self.spec.layers))
 
     def forward(self, input, ratio=None, sdf_only=False):
         """`sdf_only=True` (extension): evaluate only the d_out distance rows of the last layer -- for callers that never

@@ -86,6 +86,56 @@ def test_mesh_rasteriser_vs_pytorch3d_restatement_and_find_surface_ps():
     assert torch.allclose(p0, exp, atol=1e-6)
 
 
+def test_mesh_rasteriser_long_thin_and_huge_faces():
+    """The wave-per-face pass of the mesh rasteriser (boxes of more than 32 pixel centres) walks, per row, only the columns between the two
+    edge crossings of that row: long thin faces (the stretched faces of a template whose neighbouring vertices follow different bones),
+    faces across the whole image, horizontal / vertical edges exactly on pixel-centre lines, vertices outside the image, and faces with a
+    vertex BEHIND the camera (unclipped as in pytorch3d 0.4.0: the passing pixels are not the projected triangle's interior there, so
+    those faces keep the test of every pixel centre of the box) -- all against the pytorch3d restatement, pixel for pixel."""
+    from selfreconcode_amd.ops import rasterize_meshes
+    H = W = 160
+    g = np.random.default_rng(7)
+    V = 400
+    xy = g.uniform(-1.3, 1.3, (1, V, 2)).astype(np.float32)
+    z = g.uniform(0.6, 3.0, (1, V)).astype(np.float32)
+    faces = []
+    for _ in range(120):                                               # thin slivers: two vertices close together, the third far away
+        a = g.integers(0, V - 2)
+        xy[0, a + 1] = xy[0, a] + g.uniform(-0.02, 0.02, 2)
+        faces.append([a, a + 1, g.integers(0, V)])
+    faces += [list(g.choice(V, 3, replace=False)) for _ in range(60)]  # arbitrary (mostly huge) faces
+    # edges exactly on pixel-centre lines: y = 1 - (2 r + 1) / H and x = 1 - (2 c + 1) / W
+    yl, xl = 1.0 - (2 * 37 + 1) / H, 1.0 - (2 * 91 + 1) / W
+    xy[0, 0] = [-0.9, yl]; xy[0, 1] = [0.8, yl]; xy[0, 2] = [0.1, yl + 0.31]; faces.append([0, 1, 2])
+    xy[0, 3] = [xl, -0.7]; xy[0, 4] = [xl, 0.9]; xy[0, 5] = [xl - 0.4, 0.2]; faces.append([3, 4, 5])
+    for k in (10, 11, 12, 13):                                          # a vertex behind the camera
+        z[0, k] = -0.7
+        faces.append([k, 40 + k, 80 + k])
+    faces = np.asarray(faces, np.int64)
+    ref_p2f, ref_bary, ref_z = ro.rasterize_meshes(np.concatenate([xy, z[..., None]], -1), faces, H, W)
+    fr = rasterize_meshes(torch.from_numpy(xy).to(DEV), torch.from_numpy(z).to(DEV), torch.from_numpy(faces).to(DEV), H, W)
+    p2f = fr.pix_to_face.cpu().numpy(); bary = fr.bary_coords.cpu().numpy()
+    cover = (ref_p2f >= 0).mean()
+    assert cover > 0.5                                                 # the faces do cover a large part of the image
+    same = p2f == ref_p2f
+    # coverage must be identical; the winning face may differ only where two faces tie in depth to the last bits
+    assert np.array_equal(p2f >= 0, ref_p2f >= 0), int(((p2f >= 0) != (ref_p2f >= 0)).sum())
+    assert same.mean() > 0.999, same.mean()
+    hit = (same & (ref_p2f >= 0))[..., 0]
+    assert np.allclose(bary[..., 0, :][hit], ref_bary[..., 0, :][hit], atol=5e-5)
+    print("coverage %.3f, identical winners %.5f" % (cover, same.mean()))
+    # faces with TWO vertices behind the camera pass pixels OUTSIDE their projected triangle (the signs of the perspective-corrected
+    # barycentrics flip): single faces whose passing region the restatement says is 700-1000 pixel centres of a 96 x 96 image
+    for seed in (43, 129, 141, 191):
+        g = np.random.default_rng(seed)
+        xy1 = g.uniform(-0.9, 0.9, (1, 3, 2)).astype(np.float32); z1 = g.uniform(0.6, 3.0, (1, 3)).astype(np.float32)
+        z1[0, :2] = -g.uniform(0.2, 2.0, 2).astype(np.float32)
+        f1 = np.array([[0, 1, 2]], np.int64)
+        r1 = ro.rasterize_meshes_loop(np.concatenate([xy1, z1[..., None]], -1), f1, 96, 96)[0]
+        p1 = rasterize_meshes(torch.from_numpy(xy1).to(DEV), torch.from_numpy(z1).to(DEV), torch.from_numpy(f1).to(DEV), 96, 96).pix_to_face.cpu().numpy()
+        assert int((r1 >= 0).sum()) > 500 and np.array_equal(p1, r1), (seed, int((r1 >= 0).sum()), int((p1 != r1).sum()))
+
+
 def test_rasterisers_edge_cases():
     from selfreconcode_amd.ops import rasterize_meshes, points_silhouette
     cam = _camera(32, 32)
