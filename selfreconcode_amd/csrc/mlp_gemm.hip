@@ -18,6 +18,7 @@
 // buffer and tile t feeds the MFMAs; the one barrier per tile sits in the middle of the MFMA stream.
 #include "sr_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -93,6 +94,9 @@ struct TileLoader {
 #pragma unroll
     for (int j = 0; j < NLOADS; ++j) reg[j] = *reinterpret_cast<const f32x4*>(p[j] + gkc);
   }
+  // KTAIL = false: K is a multiple of BK (every 512-wide layer), no float4 reaches past K and the four selects per slot -- 32 VALU
+  // operations per thread and step, next to 64 MFMAs -- are not compiled in.
+  template <bool KTAIL = true>
   __device__ __forceinline__ void store(float* __restrict__ lds, int k0, const f32x4 (&reg)[NLOADS]) const {
     const int nvalid = K - (k0 + kq4);      // floats of this float4 inside [0,K): >= 4 keeps all, <= 0 keeps none
 #pragma unroll
@@ -100,7 +104,7 @@ struct TileLoader {
       const int idx = threadIdx.x + j * THREADS;
       const int row = idx >> 3;
       f32x4 v = reg[j];
-      v.x = nvalid > 0 ? v.x : 0.f; v.y = nvalid > 1 ? v.y : 0.f; v.z = nvalid > 2 ? v.z : 0.f; v.w = nvalid > 3 ? v.w : 0.f;
+      if (KTAIL) { v.x = nvalid > 0 ? v.x : 0.f; v.y = nvalid > 1 ? v.y : 0.f; v.z = nvalid > 2 ? v.z : 0.f; v.w = nvalid > 3 ? v.w : 0.f; }
       if (ROWS * 8 % THREADS == 0 || row < ROWS) *reinterpret_cast<f32x4*>(lds + row * LDSP + kq4) = v;
     }
   }
@@ -281,7 +285,7 @@ __device__ __forceinline__ void epilogue_interior_act(const sr_gemm_args& g, f32
 // C = epilogue(A[M,K] * B[N,K]^T)
 // One output tile (workgroup-wide).  `wg` is the linear tile index of this launch / layer; `smem` the workgroup's LDS
 // (Cfg::kLdsFloats floats).  Called once per workgroup by gemm_nt_kernel and in a loop by the persistent chain kernel.
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool KTAIL = true>
 __device__ __forceinline__ void gemm_nt_tile(const sr_gemm_args& g, int wg, float* __restrict__ smem) {
   using C_ = Cfg<WM, WN, TM, TN>;
   auto As = [&](int buf) -> float* { return smem + buf * (C_::BM * LDSP); };
@@ -346,14 +350,14 @@ __device__ __forceinline__ void gemm_nt_tile(const sr_gemm_args& g, int wg, floa
   f32x4 ra0[C_::kALoads], rb0[C_::kBLoads], ra1[C_::kALoads], rb1[C_::kBLoads];
   la.load(0, ra0); lb.load(0, rb0);
   la.load(BK, ra1); lb.load(BK, rb1);
-  la.store(As(0), 0, ra0); lb.store(Bs(0), 0, rb0);
+  la.template store<KTAIL>(As(0), 0, ra0); lb.template store<KTAIL>(Bs(0), 0, rb0);
   __syncthreads();
   read_frags(As(0), Bs(0), 0, fa0, fb0);
   auto step = [&](int t, f32x4 (&ain)[C_::kALoads], f32x4 (&bin)[C_::kBLoads], const f32x4 (&aout)[C_::kALoads],
                   const f32x4 (&bout)[C_::kBLoads]) {
     const int cur = t & 1;
     la.load((t + 2) * BK, ain); lb.load((t + 2) * BK, bin);
-    la.store(As(cur ^ 1), (t + 1) * BK, aout); lb.store(Bs(cur ^ 1), (t + 1) * BK, bout);
+    la.template store<KTAIL>(As(cur ^ 1), (t + 1) * BK, aout); lb.template store<KTAIL>(Bs(cur ^ 1), (t + 1) * BK, bout);
     read_frags(As(cur), Bs(cur), 2, fa1, fb1);
     mfma_kk(fa0[0], fb0[0]);
     mfma_kk(fa0[1], fb0[1]);
@@ -413,13 +417,16 @@ __device__ __forceinline__ void gemm_nt_tile(const sr_gemm_args& g, int wg, floa
   }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool KTAIL>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_kernel(sr_gemm_args g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // (Tried in round 3: delaying the second workgroup of every CU by 0.1 - 0.6 of a tile at the start of a launch, so that the two
   // co-resident workgroups do not run their prologues / epilogues in phase -- no effect, 119.0 +- 0.4 TFLOP/s at every delay.)
-  gemm_nt_tile<WM, WN, TM, TN>(g, blockIdx.x, smem);
+  gemm_nt_tile<WM, WN, TM, TN, KTAIL>(g, blockIdx.x, smem);
 }
+
+// (Tried in round 4: the same tiles walked by a RESIDENT grid of 512 workgroups with a stride loop -- 135.4 against 135.3 TFLOP/s on
+// 262144 x 512 x 512: retiring a workgroup and placing a fresh one is not where the time goes.)
 
 // ------------------------------------------------------------------------------------------------
 // Split-bf16 ("bf16x3") form of the same tile, opt-in (sr_gemm_args::B3): every fp32 operand is written as the sum of three bf16
@@ -1017,37 +1024,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
   const float* zcol = g.Z + (n0 + cqz < zmax ? n0 + cqz : zmax);
   const float* xcol = g.A + (k0 + cqx < xmax ? k0 + cqx : xmax);
   f32x4 rz[TLZ], rx[TLX];
-  auto load = [&](int r0) {
+  // Two forms of the step, chosen per workgroup (block-uniform):
+  //   TAIL = true   the slab's row count is not a multiple of TBR (the last slab of a launch): per-lane row clamp on the loads, per-lane
+  //                 zeroing of the rows past the end when the registers go to LDS;
+  //   TAIL = false  every step is a full tile: a thread's load address is its base pointer + (uniform row offset) * pitch -- no per-lane
+  //                 multiply, clamp or select.  The prefetches past the slab's last tile (never used) re-read that last tile.
+  // The ISA of the single form had 192 VALU operations per step next to its 64 MFMAs (16 quarter-rate v_mul_lo_u32, 32 selects, 26
+  // bias adds in every workgroup although only the k0 == 0 column of tiles folds a bias gradient): the kernel ran at 118 TFLOP/s where
+  // the NT tile code (12 VALU operations per step) reaches 135.
+  const float* zbase[TLZ];
+  const float* xbase[TLX];
 #pragma unroll
-    for (int j = 0; j < TLZ; ++j) {
-      int gr = r0 + lrz + j * (256 / ZT);
-      gr = gr < r_end ? gr : r_end - 1;
-      rz[j] = *reinterpret_cast<const f32x4*>(zcol + (int64_t)gr * g.ldz);
-    }
+  for (int j = 0; j < TLZ; ++j) zbase[j] = zcol + (int64_t)(lrz + j * (256 / ZT)) * g.ldz;
 #pragma unroll
-    for (int j = 0; j < TLX; ++j) {
-      int gr = r0 + lrx + j * (256 / XT);
-      gr = gr < r_end ? gr : r_end - 1;
-      rx[j] = *reinterpret_cast<const f32x4*>(xcol + (int64_t)gr * g.lda);
+  for (int j = 0; j < TLX; ++j) xbase[j] = xcol + (int64_t)(lrx + j * (256 / XT)) * g.lda;
+  const int last_full = r_end - TBR;                  // start row of the slab's last full tile (TAIL = false)
+  auto load = [&](int r0, auto tail) {
+    if constexpr (decltype(tail)::value) {
+#pragma unroll
+      for (int j = 0; j < TLZ; ++j) {
+        int gr = r0 + lrz + j * (256 / ZT);
+        gr = gr < r_end ? gr : r_end - 1;
+        rz[j] = *reinterpret_cast<const f32x4*>(zcol + (int64_t)gr * g.ldz);
+      }
+#pragma unroll
+      for (int j = 0; j < TLX; ++j) {
+        int gr = r0 + lrx + j * (256 / XT);
+        gr = gr < r_end ? gr : r_end - 1;
+        rx[j] = *reinterpret_cast<const f32x4*>(xcol + (int64_t)gr * g.lda);
+      }
+    } else {
+      const int rc = r0 < last_full ? r0 : last_full;                       // (uniform)
+      const int64_t oz = (int64_t)rc * g.ldz, ox = (int64_t)rc * g.lda;     // (uniform: scalar multiplies)
+#pragma unroll
+      for (int j = 0; j < TLZ; ++j) rz[j] = *reinterpret_cast<const f32x4*>(zbase[j] + oz);
+#pragma unroll
+      for (int j = 0; j < TLX; ++j) rx[j] = *reinterpret_cast<const f32x4*>(xbase[j] + ox);
     }
   };
-  auto store = [&](int buf, int r0) {
+  auto store = [&](int buf, int r0, auto tail) {
     float* zs = Zs(buf);
     float* xs = Xs(buf);
 #pragma unroll
     for (int j = 0; j < TLZ; ++j) {
       const int row = lrz + j * (256 / ZT);
-      const bool ok = r0 + row < r_end;
       f32x4 z = rz[j];
-      z.x = ok ? z.x : 0.f; z.y = ok ? z.y : 0.f; z.z = ok ? z.z : 0.f; z.w = ok ? z.w : 0.f;
+      if constexpr (decltype(tail)::value) {
+        const bool ok = r0 + row < r_end;
+        z.x = ok ? z.x : 0.f; z.y = ok ? z.y : 0.f; z.z = ok ? z.z : 0.f; z.w = ok ? z.w : 0.f;
+      }
       *reinterpret_cast<f32x4*>(zs + row * C::ZLD + cqz) = z;
     }
 #pragma unroll
     for (int j = 0; j < TLX; ++j) {
       const int row = lrx + j * (256 / XT);
-      const bool ok = r0 + row < r_end;
       f32x4 x = rx[j];
-      x.x = ok ? x.x : 0.f; x.y = ok ? x.y : 0.f; x.z = ok ? x.z : 0.f; x.w = ok ? x.w : 0.f;
+      if constexpr (decltype(tail)::value) {
+        const bool ok = r0 + row < r_end;
+        x.x = ok ? x.x : 0.f; x.y = ok ? x.y : 0.f; x.z = ok ? x.z : 0.f; x.w = ok ? x.w : 0.f;
+      }
       *reinterpret_cast<f32x4*>(xs + row * C::XLD + cqx) = x;
     }
   };
@@ -1086,10 +1121,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
   };
   const int nsteps = (r_end - r_begin + TBR - 1) / TBR;
-  if (nsteps > 0) {   // (block-uniform)
-    load(r_begin);
-    store(0, r_begin);
-    load(r_begin + TBR);
+  auto run = [&](auto tail, auto bias) {
+    load(r_begin, tail);
+    store(0, r_begin, tail);
+    load(r_begin + TBR, tail);
     __syncthreads();
     read_half(0, 0, z0a, z1a, x0a, x1a);
     // Step t, as in the NT kernel: tile t+1 goes registers -> LDS, the register stage is refilled with tile t+2, the second
@@ -1097,8 +1132,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     // barrier, the first-half fragments of tile t+1, and the second half of the MFMAs.
     for (int t = 0; t < nsteps; ++t) {
       const int cur = t & 1;
-      store(cur ^ 1, r_begin + (t + 1) * TBR);
-      load(r_begin + (t + 2) * TBR);
+      store(cur ^ 1, r_begin + (t + 1) * TBR, tail);
+      load(r_begin + (t + 2) * TBR, tail);
       read_half(cur, 1, z0b, z1b, x0b, x1b);
       mfma_half(z0a, z1a, x0a, x1a);
 #pragma unroll
@@ -1117,14 +1152,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      bias_half(z0a, z1a);
+      if constexpr (decltype(bias)::value) bias_half(z0a, z1a);
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       read_half(cur ^ 1, 0, z0a, z1a, x0a, x1a);
       __builtin_amdgcn_sched_barrier(0);
       mfma_half(z0b, z1b, x0b, x1b);
-      bias_half(z0b, z1b);
+      if constexpr (decltype(bias)::value) bias_half(z0b, z1b);
       __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (nsteps > 0) {   // (block-uniform)
+    const bool tail = ((r_end - r_begin) % TBR) != 0;
+    if (tail) {
+      if (do_bias) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{});
+    } else {
+      if (do_bias) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{});
     }
   }
   __syncthreads();
@@ -1244,8 +1287,12 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
   do {                                                                                                                      \
     using C_ = Cfg<WM, WN, TM, TN>;                                                                                         \
     const int nwg = (int)(sr_cdiv(g.M, C_::BM) * sr_cdiv(ncols, C_::BN));                                                   \
-    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float),     \
-                       (hipStream_t)stream, g);                                                                             \
+    if (g.K % BK)                                                                                                           \
+      hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), \
+                         (hipStream_t)stream, g);                                                                           \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, false>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), \
+                         (hipStream_t)stream, g);                                                                           \
   } while (0)
   // opt-in split-bf16 path: B pre-split (B3), wide output, enough rows to fill the machine with 128 x 128 tiles
   static const int bf16x3_min_rows = getenv("SR_BF16X3_MIN_ROWS") ? atoi(getenv("SR_BF16X3_MIN_ROWS")) : 8192;
@@ -1332,8 +1379,9 @@ __global__ __launch_bounds__(ChainCfg::kThreads) __attribute__((amdgpu_waves_per
   const int t1 = nprob > 1 ? rows * ((g1.N + (g1.mode == SR_EPI_FWD ? g1.naux_fwd : 0) + ChainCfg::BN - 1) / ChainCfg::BN) : 0;
   const int t = blockIdx.x;
   if (t >= t0 + t1) return;
-  if (t < t0) { g0.M = M; gemm_nt_tile<2, 2, 1, 1>(g0, t, smem); }
-  else { g1.M = M; gemm_nt_tile<2, 2, 1, 1>(g1, t - t0, smem); }
+  // (block-uniform: the 512-wide layers take the tile code without the K-tail selects)
+  if (t < t0) { g0.M = M; if (g0.K % BK) gemm_nt_tile<2, 2, 1, 1, true>(g0, t, smem); else gemm_nt_tile<2, 2, 1, 1, false>(g0, t, smem); }
+  else { g1.M = M; if (g1.K % BK) gemm_nt_tile<2, 2, 1, 1, true>(g1, t - t0, smem); else gemm_nt_tile<2, 2, 1, 1, false>(g1, t - t0, smem); }
 }
 
 static int chain_grid_size() {
