@@ -729,11 +729,20 @@ def packed_weights_of(module, nlayers):
     (storage or version) and the packs are handed out as plain tensors (deferred mode), the previous answer is returned: the three networks
     are asked for their packs ~15 times per iteration, ~70 us each -- 1 ms of host time, which is wall time at one frame per rank."""
     d = module.__dict__
-    lins = d.get('_sr_lins')
-    if lins is None or len(lins) != nlayers:
-        lins = d['_sr_lins'] = [getattr(module, "lin" + str(l)) for l in range(nlayers)]
-        d['_sr_params'] = [p for lin in lins for p in ((lin.weight_v, lin.weight_g, lin.bias) if hasattr(lin, "weight_g") else (lin.weight, lin.bias)) if p is not None]
-    key = (DEFERRED_PARAM_GRADS, PLAIN_PACKS) + tuple((p.data_ptr(), p._version, p.requires_grad) for p in d['_sr_params'])
+    mods = module._modules                                   # (plain dict lookups: nn.Module.__getattr__ is ~10x slower, and a layer or a
+    lins = [mods["lin" + str(l)] for l in range(nlayers)]    #  parameter that was REPLACED since the last call must be seen)
+    params = []
+    for lin in lins:
+        P = lin._parameters
+        v = P.get('weight_v')
+        if v is not None:
+            params.append(v); params.append(P['weight_g'])
+        else:
+            params.append(P['weight'])
+        b = P.get('bias')
+        if b is not None:
+            params.append(b)
+    key = (DEFERRED_PARAM_GRADS, PLAIN_PACKS) + tuple((id(p), p.data_ptr(), p._version, p.requires_grad) for p in params)
     hit = d.get('_sr_packs')
     if hit is not None and hit[0] == key:
         return list(hit[1]), list(hit[2])
