@@ -258,6 +258,8 @@ def rasterize_meshes(verts_ndc, faces, H, W):
         if not cand:
             continue
         pix, pz, fidx, b0, b1, b2 = [np.concatenate(t) for t in zip(*cand)]
+        if pix.size == 0:                                                            # faces in the image, none covering a pixel centre
+            continue
         order = np.lexsort((fidx, pz, pix))                                           # per pixel: smallest depth, ties -> lowest face index
         pix, pz, fidx, b0, b1, b2 = pix[order], pz[order], fidx[order], b0[order], b1[order], b2[order]
         first = np.r_[True, pix[1:] != pix[:-1]]

@@ -92,3 +92,51 @@ def test_checkpoint_roundtrip(tmp_path):
     ds2 = DS(); ds2.trans = torch.zeros(4, 3, requires_grad=True)
     load_model(path, b, ds2, "cpu")
     assert torch.equal(b.sdf.lin5.weight_v, a.sdf.lin5.weight_v) and torch.equal(ds2.trans, ds.trans) and ds2.trans.requires_grad
+
+
+def test_pack_cache_follows_parameter_changes():
+    """mlp_engine.packed_weights_of hands the previous packs out again only while nothing they were made from has changed: an
+    in-place update (optimizer step), a replaced parameter and a replaced layer must each be seen (deferred mode, where the cache is on;
+    CPU tensors: the packing itself is plain torch here)."""
+    import torch
+    import torch.nn as nn
+    from selfreconcode_amd import mlp_engine as me
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin0 = nn.utils.weight_norm(nn.Linear(7, 12))
+            self.lin1 = nn.Linear(12, 3)
+    net = Net()
+    me.set_deferred_param_grads(True)
+    try:
+        W0, b0 = me.packed_weights_of(net, 2)            # first call: the autograd packs (not cached)
+        W1, b1 = me.packed_weights_of(net, 2)            # entries exist now: plain packs, cached from here on
+        W2, b2 = me.packed_weights_of(net, 2)
+        assert all(a is b for a, b in zip(W1, W2)) and '_sr_packs' in net.__dict__
+        eff = torch._weight_norm(net.lin0.weight_v, net.lin0.weight_g, 0)
+        assert torch.allclose(W2[0][:, :7], eff) and torch.allclose(W2[1][:, :12], net.lin1.weight)
+        with torch.no_grad():                             # an optimizer step: in place, version bump
+            net.lin1.weight.mul_(2.0)
+        W3, _ = me.packed_weights_of(net, 2)
+        assert torch.allclose(W3[1][:, :12], net.lin1.weight)
+        net.lin1.bias = nn.Parameter(torch.full((3,), 0.25))          # a replaced parameter
+        _, b4 = me.packed_weights_of(net, 2)
+        assert b4[1] is net.lin1.bias
+        net.lin1 = nn.Linear(12, 3)                                    # a replaced layer
+        W5, b5 = me.packed_weights_of(net, 2)
+        assert torch.allclose(W5[1][:, :12], net.lin1.weight) and b5[1] is net.lin1.bias
+    finally:
+        me.set_deferred_param_grads(False)
+
+
+def test_segmented_first_layer_bias_is_validated():
+    import pytest
+    import torch
+    from selfreconcode_amd import mlp_engine as me
+    assert me._bias_segments(None, 12, 1) is None and me._bias_segments(torch.zeros(8), 12, 1) is None
+    assert me._bias_segments(torch.zeros(3, 8), 12, 1) == (3, 4) and me._bias_segments(torch.zeros(3, 8), 24, 4) == (3, 8)
+    with pytest.raises(RuntimeError):
+        me._bias_segments(torch.zeros(5, 8), 12, 1)       # rows not divisible by the segments
+    with pytest.raises(RuntimeError):
+        me._bias_segments(torch.zeros(3, 8), 18, 4)       # a segment that would split a (primal, tangents) group
