@@ -399,7 +399,8 @@ def main():
                       "rays_converged_frac": r["rays_converged_frac"], "ms_per_step_remesh_amortised": r["ms_per_step_remesh_amortised"],
                       "what": "forward / backward-data layer GEMMs with >= 8192 rows: operands split into three bf16 terms, six products accumulated in fp32 by "
                               "v_mfma_f32_32x32x16_bf16 (error below the fp32 MFMA kernel's, tests/test_mlp_gpu.py); refiner chains, weight-gradient GEMMs and "
-                              "small launches stay exact fp32"}
+                              "small launches stay exact fp32; 256 x 256 workgroup tiles (the CU-owning tiling: reproducible next to the other streams' kernels, "
+                              "DESIGN.md 3.1; the 128 x 128 tiling of SR_BF16X3_TILE=128 is ~1.7 ms faster inside the iteration and is not)"}
 
     # configs[2] (8 frames over 8 GPUs) cannot be run on one GPU; what CAN be measured here is both ends of its strong-scaling
     # ratio: the whole 8-frame step on one GPU, and the step ONE rank of 8 would run (1 frame, the replicated template term on 1/8 of

@@ -1298,13 +1298,19 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
   static const int bf16x3_min_rows = getenv("SR_BF16X3_MIN_ROWS") ? atoi(getenv("SR_BF16X3_MIN_ROWS")) : 8192;
   if (g.B3 && ncols > 32 && g.M >= bf16x3_min_rows) {
     if ((g.ldb3 & 15) || ((uintptr_t)g.B3 & 15) || (g.plane3 & 7) || g.ldb3 < ((g.K + 15) & ~15)) return SR_EINVAL;
-    // SR_BF16X3_TILE=256: 256 x 256 workgroup tiles (128 x 128 per wave).  Alone on the machine it is the faster form (164-185 against
-    // 150-156 TFLOP/s-equivalent on 262144 x 512 x 512), inside the iteration it is not (46.8 against 45.8 ms): one workgroup per CU with
-    // 147 KB of LDS leaves no room for the weight-gradient stream's workgroups, and 87k-row launches are 2.7 rounds of 256 tiles.  So it
-    // is a tuning switch, not the default.
-    static const int tile_sel = getenv("SR_BF16X3_TILE") ? atoi(getenv("SR_BF16X3_TILE")) : 0;
+    // Two tilings.  The default is 256 x 256 workgroup tiles (128 x 128 per wave, 512 registers per wave, one workgroup per CU): alone on
+    // the machine it is the faster form (164-185 against 150-156 TFLOP/s-equivalent on 262144 x 512 x 512); inside the iteration it costs
+    // ~1 ms against the 128 x 128 tiling (one workgroup per CU with 147 KB of LDS leaves no room for the weight-gradient stream's
+    // workgroups, and 87k-row launches are 2.7 rounds of 256 tiles).  It is the default because it OWNS the CUs it runs on: the
+    // 128 x 128 tiling (SR_BF16X3_TILE=128; 244 registers, two workgroups per CU) shares CUs with other streams' kernels, and kernels
+    // that share a CU with it are disturbed -- a victim micro-kernel reads garbage back from its own stack (1.7e-3 of its evaluations,
+    // tools/valu_repro.py), the hard rasteriser loses or flips 1-3 of 291,600 pixels in ~10 % of the calls (tools/raster_repeat.py) --
+    // while the GEMM's own results stay bit-reproducible and nothing is written outside its output (tools/gemm_guard.py).  The
+    // mechanism is not identified (profiles/r04_bf16x3_hunt.md lists what was ruled out); the fp32 kernel with the same LDS and launch
+    // shape does not do it, nor does this tiling.
+    static const int tile_sel = getenv("SR_BF16X3_TILE") ? atoi(getenv("SR_BF16X3_TILE")) : 256;
     const int64_t big_tiles = sr_cdiv(g.M, Cfg3W::BM) * sr_cdiv(ncols, Cfg3W::BN);
-    if (tile_sel == 256) {
+    if (tile_sel != 128) {
       static bool attr_w = false;
       if (!attr_w) {
         if (hipFuncSetAttribute((const void*)gemm_nt_bf16x3_w128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg3W::kLdsBytes) != hipSuccess ||

@@ -380,6 +380,8 @@ class OptimNetwork(nn.Module):
         self._mark('start')
         defTmpVs = self.deformer(self.TmpVs[None, :, :].expand(N, -1, 3), defconds, ratio=ratio)
         self._mark('template deformed')
+        if debug is not None:
+            debug['defTmpVs'] = defTmpVs.detach().clone()
         self.info['pc_loss'] = {}
 
         # Two streams.  The template branch (silhouette, mask loss, its backward, the template SGD step, |f(TmpVs)|) is a few
@@ -415,6 +417,8 @@ class OptimNetwork(nn.Module):
                     self._mark('sel: projected')
                     frags = rasterize_meshes(xy, z, self.Tmpfs, H, W)
                     self._mark('sel: rasterised')
+                    if debug is not None:
+                        debug.update(proj_xy=xy.clone(), proj_z=z.clone(), pix_to_face=(frags[0] if isinstance(frags, (tuple, list)) else frags.pix_to_face).clone())
                     batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(seedVs, self.Tmpfs, frags)
                     self._mark('sel: seeds found')
                 else:

@@ -445,11 +445,12 @@ def test_bf16x3_gemm_is_fp32_accurate():
     print("errors / sum|a||b| (fp32 MFMA, bf16x3):", worst)
 
 
-def test_bf16x3_wide_wave_tile_variant_in_a_subprocess():
-    """SR_BF16X3_TILE=256 (128 x 128 wave tiles, accumulators in AGPRs) is read once per process: the accuracy test above is re-run
-    under it in a child process (ragged shapes included: edge tiles go through the generic epilogue band by band)."""
+def test_bf16x3_other_tiling_in_a_subprocess():
+    """The tiling of the split-bf16 GEMM is read once per process (SR_BF16X3_TILE; default 256 = 128 x 128 wave tiles with the
+    accumulators in AGPRs, edge tiles through the generic epilogue band by band): the accuracy test above ran under the default, a
+    child process re-runs it under the 128 x 128 workgroup tiling."""
     import os, subprocess, sys
-    env = dict(os.environ, SR_BF16X3_TILE="256")
+    env = dict(os.environ, SR_BF16X3_TILE="128")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_bf16x3_gemm_is_fp32_accurate"], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,0 +1,164 @@
+// Is plain VALU arithmetic reproducible while another stream's kernel keeps the matrix cores busy?  (tools/valu_repro.py)
+// Every thread evaluates ONE out-of-line function twice on the same bits and counts the evaluations whose two results differ.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+__device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
+
+__device__ __attribute__((noinline)) float f_fma(float a, float b, float c, float d) { return (a - c) * (d - b) - (b - d) * (c - a) + a * b; }
+__device__ __attribute__((noinline)) float f_div(float a, float b, float c, float d) { return a / b + c / d; }
+__device__ __attribute__((noinline)) float f_rcp(float a, float b, float c, float d) { return __builtin_amdgcn_rcpf(b) * a + __builtin_amdgcn_rcpf(d) * c; }
+__device__ __attribute__((noinline)) float f_minmax(float a, float b, float c, float d) { return fmaxf(a, fmaxf(b, c)) - fminf(d, fminf(a, b)); }
+__device__ __attribute__((noinline)) float f_sqrt(float a, float b, float c, float d) { return sqrtf(fabsf(a)) + sqrtf(fabsf(c)) * b + d; }
+__device__ __attribute__((noinline)) float f_idiv(float a, float b, float c, float d) {
+  const long long i = (long long)(fabsf(a) * 1.0e6f) + 12345, F = (long long)(fabsf(b) * 1.0e3f) + 77;
+  return (float)(i / F) + (float)(i % F) + c + d;
+}
+__device__ __attribute__((noinline)) float f_cmp(float a, float b, float c, float d) {      // compares + selects (v_cmp / v_cndmask through VCC / SGPR pairs)
+  float r = 0.f;
+  r += (a > b) ? c : d; r += (b > c && a > 0.f) ? a : b; r += (c < d || b < 0.f) ? d : a; r += (a * b > c * d) ? 1.f : 2.f;
+  return r;
+}
+
+// the rasteriser's pixel test (csrc/raster.hip::face_hit), arguments in registers / through the stack
+struct Tri9 { float x0, y0, z0, x1, y1, z1, x2, y2, z2; };
+__device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) { return (px - ax) * (by - ay) - (py - ay) * (bx - ax); }
+__device__ __forceinline__ float hit_body(const Tri9& t, float xf, float yf) {
+  const float kEps = 1e-8f;
+  const float den = edge_fn(t.x2, t.y2, t.x0, t.y0, t.x1, t.y1) + kEps;
+  const float w0 = edge_fn(xf, yf, t.x1, t.y1, t.x2, t.y2) / den, w1 = edge_fn(xf, yf, t.x2, t.y2, t.x0, t.y0) / den, w2 = edge_fn(xf, yf, t.x0, t.y0, t.x1, t.y1) / den;
+  const float t0 = w0 * t.z1 * t.z2, t1 = t.z0 * w1 * t.z2, t2 = t.z0 * t.z1 * w2;
+  const float dn = fmaxf(t0 + t1 + t2, kEps);
+  const float b0 = t0 / dn, b1 = t1 / dn, b2 = t2 / dn;
+  const float pz = b0 * t.z0 + b1 * t.z1 + b2 * t.z2;
+  return (b0 > 0.f && b1 > 0.f && b2 > 0.f && pz >= 0.f) ? b0 + 2.f * b1 + 4.f * b2 : -pz;
+}
+__device__ __attribute__((noinline)) float f_hit_regs(float x0, float y0, float z0, float x1, float y1, float z1, float x2, float y2, float z2, float xf, float yf) {
+  const Tri9 t = {x0, y0, z0, x1, y1, z1, x2, y2, z2};
+  return hit_body(t, xf, yf);
+}
+__device__ __attribute__((noinline)) void f_hit_stack(const Tri9& t, float xf, float yf, float& out) { out = hit_body(t, xf, yf); }
+
+template <int V>
+__device__ __forceinline__ float run(float a, float b, float c, float d) {
+  if (V == 0) return f_fma(a, b, c, d);
+  if (V == 1) return f_div(a, b, c, d);
+  if (V == 2) return f_rcp(a, b, c, d);
+  if (V == 3) return f_minmax(a, b, c, d);
+  if (V == 4) return f_sqrt(a, b, c, d);
+  if (V == 5) return f_idiv(a, b, c, d);
+  if (V == 6) return f_cmp(a, b, c, d);
+  // a small triangle around (a, b) with depths ~ 2 + c, tested at a point near it
+  const float x0 = opaque(a), y0 = opaque(b), x1 = opaque(a + 0.01f * c), y1 = opaque(b + 0.003f), x2 = opaque(a + 0.002f), y2 = opaque(b + 0.01f * d);
+  const float z0 = opaque(2.f + 0.1f * c), z1 = opaque(2.f + 0.1f * d), z2 = opaque(2.1f), xf = opaque(a + 0.004f), yf = opaque(b + 0.004f);
+  if (V == 7) return f_hit_regs(x0, y0, z0, x1, y1, z1, x2, y2, z2, xf, yf);
+  Tri9 t = {x0, y0, z0, x1, y1, z1, x2, y2, z2};
+  float out;
+  f_hit_stack(t, xf, yf, out);
+  return out;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void repro_kernel(const float4* __restrict__ in, long n, unsigned long long* __restrict__ counters, int rounds) {
+  unsigned long long bad = 0;
+  unsigned int worst = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = in[i];
+    for (int r = 0; r < rounds; ++r) {
+      const float s = 1.0f + 0.125f * (float)r;
+      const float x = run<V>(opaque(v.x * s), opaque(v.y), opaque(v.z), opaque(v.w * s));
+      const float y = run<V>(opaque(v.x * s), opaque(v.y), opaque(v.z), opaque(v.w * s));
+      if (__float_as_uint(x) != __float_as_uint(y)) {
+        ++bad;
+        const unsigned int dd = __float_as_uint(fabsf(x - y) / fmaxf(fabsf(x), 1e-30f));
+        worst = dd > worst ? dd : worst;
+      }
+    }
+  }
+  if (bad) { atomicAdd(&counters[2 * V], bad); atomicMax((unsigned int*)&counters[2 * V + 1], worst); }
+}
+// ---- synthetic neighbours: one instruction class each, ~1 ms per launch
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void agg_mfma_bf16(float* out, int iters) {
+  bf16x8_t a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (float)(threadIdx.x + i)); b[i] = (__bf16)(0.002f * (float)(threadIdx.x ^ i)); }
+  f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, c3, 0, 0, 0);
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+}
+__global__ __launch_bounds__(256) void agg_mfma_f32(float* out, int iters) {
+  const float a = 0.001f * (float)threadIdx.x, b = 0.002f * (float)(threadIdx.x ^ 5);
+  f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, b, c3, 0, 0, 0);
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+}
+__global__ __launch_bounds__(256) void agg_lds(float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  u32x4 acc = {0, 0, 0, 0};
+  const int row = threadIdx.x & 127, half = threadIdx.x >> 7;
+  for (int i = 0; i < iters; ++i) {
+    *reinterpret_cast<u32x2*>(sm + row * 48 + half * 8 + (i & 1) * 36864) = u32x2{(unsigned)i, threadIdx.x};
+    *reinterpret_cast<u32x4*>(sm + 6144 + row * 48 + half * 16 + (i & 1) * 36864) = u32x4{(unsigned)i, 1u, 2u, threadIdx.x};
+    __syncthreads();
+    const u32x4 v = *reinterpret_cast<const u32x4*>(sm + ((row * 7) & 127) * 48 + half * 16 + (i & 1) * 36864);
+    acc += v;
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = (float)(acc.x + acc.y + acc.z + acc.w);
+}
+__global__ __launch_bounds__(256) void agg_cvt(float* out, int iters) {
+  float x = 0.37f * (float)threadIdx.x, y = 1.0f;
+  unsigned int acc = 0;
+  for (int i = 0; i < iters; ++i) {
+    const unsigned int h = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{x, y}, bf16x2_t));
+    x = x * 1.0001f - __builtin_bit_cast(float, h << 16) * 0.5f; y = y * 0.9999f + __builtin_bit_cast(float, h & 0xffff0000u) * 0.25f;
+    acc ^= h;
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = x + y + (float)acc;
+}
+}  // namespace
+extern "C" int valu_repro_neighbour(int kind, float* out, int iters, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)agg_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 73728); attr = true; }
+  switch (kind) {
+    case 0: hipLaunchKernelGGL(agg_mfma_bf16, dim3(2048), dim3(256), 0, st, out, iters); break;
+    case 1: hipLaunchKernelGGL(agg_mfma_f32, dim3(2048), dim3(256), 0, st, out, iters); break;
+    case 2: hipLaunchKernelGGL(agg_lds, dim3(2048), dim3(256), 73728, st, out, iters); break;
+    case 3: hipLaunchKernelGGL(agg_cvt, dim3(2048), dim3(256), 0, st, out, iters); break;
+    default: return 1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+namespace {
+}
+extern "C" int valu_repro_launch(int variant, const float* in, long n, unsigned long long* counters, int rounds, void* stream) {
+  const dim3 grid(2048), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const float4* p = (const float4*)in;
+  switch (variant) {
+    case 0: hipLaunchKernelGGL(repro_kernel<0>, grid, block, 0, st, p, n, counters, rounds); break;
+    case 1: hipLaunchKernelGGL(repro_kernel<1>, grid, block, 0, st, p, n, counters, rounds); break;
+    case 2: hipLaunchKernelGGL(repro_kernel<2>, grid, block, 0, st, p, n, counters, rounds); break;
+    case 3: hipLaunchKernelGGL(repro_kernel<3>, grid, block, 0, st, p, n, counters, rounds); break;
+    case 4: hipLaunchKernelGGL(repro_kernel<4>, grid, block, 0, st, p, n, counters, rounds); break;
+    case 5: hipLaunchKernelGGL(repro_kernel<5>, grid, block, 0, st, p, n, counters, rounds); break;
+    case 6: hipLaunchKernelGGL(repro_kernel<6>, grid, block, 0, st, p, n, counters, rounds); break;
+    case 7: hipLaunchKernelGGL(repro_kernel<7>, grid, block, 0, st, p, n, counters, rounds); break;
+    case 8: hipLaunchKernelGGL(repro_kernel<8>, grid, block, 0, st, p, n, counters, rounds); break;
+    default: return 1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
