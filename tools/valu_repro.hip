@@ -59,6 +59,39 @@ __device__ __forceinline__ float run(float a, float b, float c, float d) {
   return out;
 }
 
+// pixel test with its 11 arguments sent through memory and read back: a private slice of a GLOBAL buffer (V = 9) or of LDS (V = 10)
+__device__ float* g_roundtrip;     // set by valu_repro_set_buffer: 2048 * 256 * 16 floats
+template <int V>
+__device__ __forceinline__ float run_mem(float a, float b, float c, float d, float* lds) {
+  const float x0 = a, y0 = b, x1 = a + 0.01f * c, y1 = b + 0.003f, x2 = a + 0.002f, y2 = b + 0.01f * d;
+  const float z0 = 2.f + 0.1f * c, z1 = 2.f + 0.1f * d, z2 = 2.1f, xf = a + 0.004f, yf = b + 0.004f;
+  volatile float* m = V == 9 ? g_roundtrip + ((long)blockIdx.x * 256 + threadIdx.x) * 16 : lds + threadIdx.x * 12;
+  m[0] = x0; m[1] = y0; m[2] = z0; m[3] = x1; m[4] = y1; m[5] = z1; m[6] = x2; m[7] = y2; m[8] = z2; m[9] = xf; m[10] = yf;
+  const Tri9 t = {m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8]};
+  return hit_body(t, m[9], m[10]);
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void repro_mem_kernel(const float4* __restrict__ in, long n, unsigned long long* __restrict__ counters, int rounds) {
+  __shared__ float lds[256 * 12];
+  unsigned long long bad = 0;
+  unsigned int worst = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = in[i];
+    for (int r = 0; r < rounds; ++r) {
+      const float s = 1.0f + 0.125f * (float)r;
+      const float x = run_mem<V>(opaque(v.x * s), opaque(v.y), opaque(v.z), opaque(v.w * s), lds);
+      const float y = run_mem<V>(opaque(v.x * s), opaque(v.y), opaque(v.z), opaque(v.w * s), lds);
+      if (__float_as_uint(x) != __float_as_uint(y)) {
+        ++bad;
+        const unsigned int dd = __float_as_uint(fabsf(x - y) / fmaxf(fabsf(x), 1e-30f));
+        worst = dd > worst ? dd : worst;
+      }
+    }
+  }
+  if (bad) { atomicAdd(&counters[2 * V], bad); atomicMax((unsigned int*)&counters[2 * V + 1], worst); }
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void repro_kernel(const float4* __restrict__ in, long n, unsigned long long* __restrict__ counters, int rounds) {
   unsigned long long bad = 0;
@@ -144,6 +177,9 @@ extern "C" int valu_repro_neighbour(int kind, float* out, int iters, void* strea
 }
 namespace {
 }
+extern "C" int valu_repro_set_buffer(float* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_roundtrip), &buf, sizeof(buf)) == hipSuccess ? 0 : 2;
+}
 extern "C" int valu_repro_launch(int variant, const float* in, long n, unsigned long long* counters, int rounds, void* stream) {
   const dim3 grid(2048), block(256);
   hipStream_t st = (hipStream_t)stream;
@@ -158,6 +194,8 @@ extern "C" int valu_repro_launch(int variant, const float* in, long n, unsigned 
     case 6: hipLaunchKernelGGL(repro_kernel<6>, grid, block, 0, st, p, n, counters, rounds); break;
     case 7: hipLaunchKernelGGL(repro_kernel<7>, grid, block, 0, st, p, n, counters, rounds); break;
     case 8: hipLaunchKernelGGL(repro_kernel<8>, grid, block, 0, st, p, n, counters, rounds); break;
+    case 9: hipLaunchKernelGGL(repro_mem_kernel<9>, grid, block, 0, st, p, n, counters, rounds); break;
+    case 10: hipLaunchKernelGGL(repro_mem_kernel<10>, grid, block, 0, st, p, n, counters, rounds); break;
     default: return 1;
   }
   return hipGetLastError() == hipSuccess ? 0 : 2;

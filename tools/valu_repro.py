@@ -1,6 +1,6 @@
-"""VALU reproducibility next to the layer GEMMs of another stream (see tools/valu_repro.hip).  For each of 9 small out-of-line functions
+"""VALU reproducibility next to the layer GEMMs of another stream (see tools/valu_repro.hip).  For each of 11 small out-of-line functions
 (products, IEEE division, v_rcp, min/max, sqrt, 64-bit integer division, compares + selects, the rasteriser's pixel test with its
-arguments in registers / on the stack): every thread evaluates it twice on the same
+arguments in registers / on the stack / written to and read back from global memory / LDS): every thread evaluates it twice on the same
 bits; counts evaluations whose two results differ -- alone, next to fp32 GEMMs, next to split-bf16 GEMMs.
     hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/valu_repro.hip -o tools/_bin/libvalu_repro.so;  python tools/valu_repro.py [reps]"""
 import ctypes
@@ -17,7 +17,10 @@ DEV = "cuda:0"
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bin", "libvalu_repro.so"))
 lib.valu_repro_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
-NAMES = ["products", "IEEE division", "v_rcp * x", "min/max", "sqrt", "int64 div/mod", "compare+select", "pixel test (registers)", "pixel test (stack)"]
+NAMES = ["products", "IEEE division", "v_rcp * x", "min/max", "sqrt", "int64 div/mod", "compare+select", "pixel test (registers)", "pixel test (stack)", "pixel test (global round trip)", "pixel test (LDS round trip)"]
+lib.valu_repro_set_buffer.argtypes = [ctypes.c_void_p]
+roundtrip = torch.zeros(2048 * 256 * 16, device=DEV)
+assert lib.valu_repro_set_buffer(roundtrip.data_ptr()) == 0
 n = 1 << 20
 torch.manual_seed(0)
 inp = (torch.randn(n, 4, device=DEV) * torch.exp(torch.randn(n, 1, device=DEV) * 2.0)).contiguous()
@@ -43,14 +46,14 @@ def arm(name, work):
         if work is not None:
             work()
         with torch.cuda.stream(side):
-            for v in range(9):
+            for v in range(11):
                 rc = lib.valu_repro_launch(v, inp.data_ptr(), n, counters.data_ptr(), 8, side.cuda_stream)
                 assert rc == 0, rc
     torch.cuda.synchronize()
     c = counters.tolist()
     total = reps * n * 8
     print(name + ":  " + ";  ".join("%s %d%s" % (NAMES[v], c[2 * v], "" if c[2 * v] == 0 else " (worst rel. diff %.1e)" % struct.unpack("f", struct.pack("I", c[2 * v + 1] & 0xffffffff))[0])
-                                 for v in range(9)) + "   [of %.1e evaluations each]" % total, flush=True)
+                                 for v in range(11)) + "   [of %.1e evaluations each]" % total, flush=True)
 
 
 def torch_mm(dtype):
