@@ -1305,9 +1305,10 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
     // 128 x 128 tiling (SR_BF16X3_TILE=128; 244 registers, two workgroups per CU) shares CUs with other streams' kernels, and kernels
     // that share a CU with it are disturbed -- a victim micro-kernel reads garbage back from its own stack (1.7e-3 of its evaluations,
     // tools/valu_repro.py), the hard rasteriser loses or flips 1-3 of 291,600 pixels in ~10 % of the calls (tools/raster_repeat.py) --
-    // while the GEMM's own results stay bit-reproducible and nothing is written outside its output (tools/gemm_guard.py).  The
-    // mechanism is not identified (profiles/r04_bf16x3_hunt.md lists what was ruled out); the fp32 kernel with the same LDS and launch
-    // shape does not do it, nor does this tiling.
+    // while the GEMM's own results stay bit-reproducible and nothing is written outside its output (tools/gemm_guard.py).  It is not
+    // this kernel's doing: a 40-line synthetic wave that mixes in-flight global loads with v_mfma_f32_32x32x16_bf16 does the same to the
+    // multi-dword memory accesses of its neighbours (tools/valu_repro.hip::agg_loads, profiles/r04_bf16x3_hunt.md); the fp32 MFMA does
+    // not.  So while it issues that instruction the kernel should not share CUs -- which this tiling, like hipBLASLt's, guarantees.
     static const int tile_sel = getenv("SR_BF16X3_TILE") ? atoi(getenv("SR_BF16X3_TILE")) : 256;
     const int64_t big_tiles = sr_cdiv(g.M, Cfg3W::BM) * sr_cdiv(ncols, Cfg3W::BN);
     if (tile_sel != 128) {

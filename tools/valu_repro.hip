@@ -71,6 +71,22 @@ __device__ __forceinline__ float run_mem(float a, float b, float c, float d, flo
   return hit_body(t, m[9], m[10]);
 }
 
+// the same through a private slice of the global buffer with 16-byte stores and loads (V = 11)
+__device__ __forceinline__ float run_mem4(float a, float b, float c, float d) {
+  const float x0 = a, y0 = b, x1 = a + 0.01f * c, y1 = b + 0.003f, x2 = a + 0.002f, y2 = b + 0.01f * d;
+  const float z0 = 2.f + 0.1f * c, z1 = 2.f + 0.1f * d, z2 = 2.1f, xf = a + 0.004f, yf = b + 0.004f;
+  volatile float4* m = reinterpret_cast<volatile float4*>(g_roundtrip + ((long)blockIdx.x * 256 + threadIdx.x) * 16);
+  float4 s0 = {x0, y0, z0, x1}, s1 = {y1, z1, x2, y2}, s2 = {z2, xf, yf, 0.f};
+  *reinterpret_cast<float4*>(const_cast<float4*>(m)) = s0; *reinterpret_cast<float4*>(const_cast<float4*>(m + 1)) = s1; *reinterpret_cast<float4*>(const_cast<float4*>(m + 2)) = s2;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float4 r0, r1, r2;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n s_waitcnt vmcnt(0)" : "=v"(r0) : "v"(m) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:16 sc0 sc1\n s_waitcnt vmcnt(0)" : "=v"(r1) : "v"(m) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:32 sc0 sc1\n s_waitcnt vmcnt(0)" : "=v"(r2) : "v"(m) : "memory");
+  const Tri9 t = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
+  return hit_body(t, r2.y, r2.z);
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void repro_mem_kernel(const float4* __restrict__ in, long n, unsigned long long* __restrict__ counters, int rounds) {
   __shared__ float lds[256 * 12];
@@ -80,8 +96,8 @@ __global__ __launch_bounds__(256) void repro_mem_kernel(const float4* __restrict
     const float4 v = in[i];
     for (int r = 0; r < rounds; ++r) {
       const float s = 1.0f + 0.125f * (float)r;
-      const float x = run_mem<V>(opaque(v.x * s), opaque(v.y), opaque(v.z), opaque(v.w * s), lds);
-      const float y = run_mem<V>(opaque(v.x * s), opaque(v.y), opaque(v.z), opaque(v.w * s), lds);
+      const float x = V == 11 ? run_mem4(opaque(v.x * s), opaque(v.y), opaque(v.z), opaque(v.w * s)) : run_mem<V>(opaque(v.x * s), opaque(v.y), opaque(v.z), opaque(v.w * s), lds);
+      const float y = V == 11 ? run_mem4(opaque(v.x * s), opaque(v.y), opaque(v.z), opaque(v.w * s)) : run_mem<V>(opaque(v.x * s), opaque(v.y), opaque(v.z), opaque(v.w * s), lds);
       if (__float_as_uint(x) != __float_as_uint(y)) {
         ++bad;
         const unsigned int dd = __float_as_uint(fabsf(x - y) / fmaxf(fabsf(x), 1e-30f));
@@ -161,7 +177,110 @@ __global__ __launch_bounds__(256) void agg_cvt(float* out, int iters) {
   }
   out[blockIdx.x * 256 + threadIdx.x] = x + y + (float)acc;
 }
+// a register-staged stream of loads (W floats each: 16 / 8 / 4 bytes), three steps in flight (the split-bf16 loop's shape), optionally
+// with 24 MFMAs per step (KIND 1: v_mfma_f32_32x32x16_bf16, KIND 2: v_mfma_f32_32x32x2_f32)
+template <int W> struct VecOf;
+template <> struct VecOf<4> { typedef float4 type; };
+template <> struct VecOf<2> { typedef float2 type; };
+template <> struct VecOf<1> { typedef float type; };
+__device__ __forceinline__ float first_of(float4 v) { return v.x + v.w; }
+__device__ __forceinline__ float first_of(float2 v) { return v.x + v.y; }
+__device__ __forceinline__ float first_of(float v) { return v; }
+template <int W, int KIND>
+__global__ __launch_bounds__(256) void agg_loads(const float* __restrict__ src_f, long nfloat, float* out, int iters) {
+  typedef typename VecOf<W>::type vec;
+  constexpr int NL = 28 / W;                       // 112 bytes per thread and step
+  const vec* __restrict__ src = reinterpret_cast<const vec*>(src_f);
+  const long nvec = nfloat / W;
+  vec st[3][NL];
+  const long stride = (long)gridDim.x * 256;
+  long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  auto load = [&](vec (&r)[NL]) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { r[j] = src[idx % nvec]; idx += stride; }
+  };
+  bf16x8_t a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (float)(threadIdx.x + i)); b[i] = (__bf16)(0.002f * (float)(threadIdx.x ^ i)); }
+  const float af = 0.001f * (float)threadIdx.x, bf = 0.002f * (float)(threadIdx.x ^ 5);
+  f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  float acc = 0.f;
+  load(st[0]); load(st[1]); load(st[2]);
+  for (int i = 0; i < iters; i += 3) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) acc += first_of(st[s][j]);
+      load(st[s]);
+      if (KIND == 1) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c1, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, c3, 0, 0, 0);
+        }
+      } else if (KIND == 2) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bf, af, c1, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af, af, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(bf, bf, c3, 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int j = 0; j < NL; ++j) acc += first_of(st[s][j]);
+  out[blockIdx.x * 256 + threadIdx.x] = acc + c0[0] + c1[1] + c2[2] + c3[3];
+}
+// the same stream with LDS as the destination of the loads (global_load_lds_dwordx4: no VGPR is written by a returning load) + the bf16 MFMAs
+__global__ __launch_bounds__(256) void agg_loads_lds(const float* __restrict__ src_f, long nfloat, float* out, int iters) {
+  __shared__ float4 sm[3][7][256];                         // 84 KB
+  const float4* __restrict__ src = reinterpret_cast<const float4*>(src_f);
+  const long nvec = nfloat / 4, stride = (long)gridDim.x * 256;
+  long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int wave = threadIdx.x >> 6;
+  auto load = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + idx % nvec),
+                                       (__attribute__((address_space(3))) void*)&sm[s][j][wave * 64], 16, 0, 0);
+      idx += stride;
+    }
+  };
+  bf16x8_t a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (float)(threadIdx.x + i)); b[i] = (__bf16)(0.002f * (float)(threadIdx.x ^ i)); }
+  f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  load(0); load(1); load(2);
+  for (int i = 0; i < iters; i += 3) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      load(s);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, c3, 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+  const float4 v = sm[1][3][threadIdx.x];
+  out[blockIdx.x * 256 + threadIdx.x] = v.x + v.w + c0[0] + c1[1] + c2[2] + c3[3];
+}
 }  // namespace
+extern "C" int valu_repro_neighbour_loads_lds(const float* src, long nfloat, float* out, int iters, void* stream) {
+  hipLaunchKernelGGL(agg_loads_lds, dim3(2048), dim3(256), 0, (hipStream_t)stream, src, nfloat, out, iters);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+extern "C" int valu_repro_neighbour_loads(int kind, int width, const float* src, long nfloat, float* out, int iters, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g(2048), b(256);
+#define SR_AGG(W, K) hipLaunchKernelGGL((agg_loads<W, K>), g, b, 0, st, src, nfloat, out, iters)
+  if (width == 4) { if (kind == 0) SR_AGG(4, 0); else if (kind == 1) SR_AGG(4, 1); else SR_AGG(4, 2); }
+  else if (width == 2) { if (kind == 0) SR_AGG(2, 0); else if (kind == 1) SR_AGG(2, 1); else SR_AGG(2, 2); }
+  else { if (kind == 0) SR_AGG(1, 0); else if (kind == 1) SR_AGG(1, 1); else SR_AGG(1, 2); }
+#undef SR_AGG
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
 extern "C" int valu_repro_neighbour(int kind, float* out, int iters, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   static bool attr = false;
@@ -196,6 +315,7 @@ extern "C" int valu_repro_launch(int variant, const float* in, long n, unsigned 
     case 8: hipLaunchKernelGGL(repro_kernel<8>, grid, block, 0, st, p, n, counters, rounds); break;
     case 9: hipLaunchKernelGGL(repro_mem_kernel<9>, grid, block, 0, st, p, n, counters, rounds); break;
     case 10: hipLaunchKernelGGL(repro_mem_kernel<10>, grid, block, 0, st, p, n, counters, rounds); break;
+    case 11: hipLaunchKernelGGL(repro_mem_kernel<11>, grid, block, 0, st, p, n, counters, rounds); break;
     default: return 1;
   }
   return hipGetLastError() == hipSuccess ? 0 : 2;

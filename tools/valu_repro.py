@@ -17,7 +17,7 @@ DEV = "cuda:0"
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bin", "libvalu_repro.so"))
 lib.valu_repro_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
-NAMES = ["products", "IEEE division", "v_rcp * x", "min/max", "sqrt", "int64 div/mod", "compare+select", "pixel test (registers)", "pixel test (stack)", "pixel test (global round trip)", "pixel test (LDS round trip)"]
+NAMES = ["products", "IEEE division", "v_rcp * x", "min/max", "sqrt", "int64 div/mod", "compare+select", "pixel test (registers)", "pixel test (stack)", "pixel test (global round trip)", "pixel test (LDS round trip)", "pixel test (global round trip, 16-byte stores)"]
 lib.valu_repro_set_buffer.argtypes = [ctypes.c_void_p]
 roundtrip = torch.zeros(2048 * 256 * 16, device=DEV)
 assert lib.valu_repro_set_buffer(roundtrip.data_ptr()) == 0
@@ -46,14 +46,14 @@ def arm(name, work):
         if work is not None:
             work()
         with torch.cuda.stream(side):
-            for v in range(11):
+            for v in range(12):
                 rc = lib.valu_repro_launch(v, inp.data_ptr(), n, counters.data_ptr(), 8, side.cuda_stream)
                 assert rc == 0, rc
     torch.cuda.synchronize()
     c = counters.tolist()
     total = reps * n * 8
     print(name + ":  " + ";  ".join("%s %d%s" % (NAMES[v], c[2 * v], "" if c[2 * v] == 0 else " (worst rel. diff %.1e)" % struct.unpack("f", struct.pack("I", c[2 * v + 1] & 0xffffffff))[0])
-                                 for v in range(11)) + "   [of %.1e evaluations each]" % total, flush=True)
+                                 for v in range(12)) + "   [of %.1e evaluations each]" % total, flush=True)
 
 
 def torch_mm(dtype):
@@ -89,6 +89,32 @@ def neighbour(kind, iters):
 
 
 w = gemm_work(196608)
+if os.environ.get("SR_VR_LOADS") == "1":
+    lib.valu_repro_neighbour_loads.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    big = torch.randn(64 << 20, device=DEV)          # 256 MB
+
+    def loads(kind, width, iters):
+        def work():
+            rc = lib.valu_repro_neighbour_loads(kind, width, big.data_ptr(), big.numel(), nb_out.data_ptr(), iters, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, rc
+        return work
+    lib.valu_repro_neighbour_loads_lds.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+
+    def loads_lds(iters):
+        def work():
+            rc = lib.valu_repro_neighbour_loads_lds(big.data_ptr(), big.numel(), nb_out.data_ptr(), iters, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, rc
+        return work
+    if os.environ.get("SR_VR_LDS_ONLY") == "1":
+        arm("next to the stream of 16-byte loads with LDS as their destination + the bf16 MFMAs", loads_lds(600))
+        arm("next to that stream + 24 v_mfma_f32_32x32x16_bf16 per step (VGPR destination, control)", loads(1, 4, 600))
+        sys.exit(0)
+    arm("next to a three-stage stream of 16-byte loads", loads(0, 4, 600))
+    arm("next to that stream + 24 v_mfma_f32_32x32x16_bf16 per step", loads(1, 4, 600))
+    arm("next to that stream + 12 v_mfma_f32_32x32x2_f32 per step", loads(2, 4, 600))
+    arm("next to a stream of 8-byte loads + the bf16 MFMAs", loads(1, 2, 600))
+    arm("next to a stream of 4-byte loads + the bf16 MFMAs", loads(1, 1, 600))
+    sys.exit(0)
 if os.environ.get("SR_VR_COMBO") == "1":
     third = torch.cuda.Stream()
     nb0, nb2 = neighbour(0, 6000), neighbour(2, 3000)
