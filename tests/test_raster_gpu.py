@@ -149,3 +149,54 @@ def test_rasterisers_edge_cases():
     assert abs(float(m[0, 7, 10]) - 1.0) < 1e-5
     (g,) = torch.autograd.grad(m.sum(), px)
     assert torch.isfinite(g).all()
+
+
+def test_mesh_rasteriser_is_reproducible_next_to_the_split_bf16_gemms():
+    """Guard for DESIGN 3.1 (round 4): a wave that mixes global loads with v_mfma_f32_32x32x16_bf16 corrupts the multi-dword memory
+    accesses of other kernels' waves on the CUs it shares with them -- with the 128 x 128 tiling of the split-bf16 GEMM the hard
+    rasteriser lost 1-3 of 291,600 pixels in ~10 % of its calls (tools/raster_repeat.py).  The mode's default tiling takes whole CUs:
+    the rasteriser, called 150 times on one mesh on a side stream while 196,608-row split-bf16 GEMMs run on the main stream, must give
+    the same answer every time (and it does next to the fp32 kernel, which is checked first)."""
+    from selfreconcode_amd import mlp_engine as me
+    from selfreconcode_amd.ops import rasterize_meshes
+    g = torch.Generator(device="cpu").manual_seed(5)
+    H = W = 540
+    n = 260                                           # a wavy sheet of n x n vertices: ~135k small faces, 1-4 pixel centres each, two layers in depth
+    u = torch.linspace(-0.9, 0.9, n)
+    gx, gy = torch.meshgrid(u, u, indexing="ij")
+    jit = (torch.rand(n, n, 2, generator=g) - 0.5) * (0.6 * 1.8 / n)
+    xy = torch.stack([gx, gy], -1) + jit
+    z = 2.0 + 0.3 * torch.sin(5 * gx) * torch.cos(4 * gy)
+    ii = torch.arange(n - 1)
+    a = (ii[:, None] * n + ii[None, :]).reshape(-1)
+    faces = torch.cat([torch.stack([a, a + 1, a + n], 1), torch.stack([a + 1, a + n + 1, a + n], 1)], 0)
+    xy2 = torch.cat([xy.reshape(-1, 2), xy.reshape(-1, 2) * 0.8 + 0.03], 0)                 # a second, nearer sheet over the middle
+    z2 = torch.cat([z.reshape(-1), z.reshape(-1) - 0.5], 0)
+    faces2 = torch.cat([faces, faces + n * n], 0)
+    xy_d, z_d, f_d = xy2[None].to(DEV).contiguous(), z2[None].to(DEV).contiguous(), faces2.to(DEV).contiguous()
+    M, N, K = 196608, 512, 512
+    A = (torch.randn(M, K, device=DEV) * 0.3).contiguous(); B = (torch.randn(N, K, device=DEV) * 0.05).contiguous()
+    C = torch.zeros(M, N, device=DEV); bias = torch.zeros(N, device=DEV)
+    planes = me.split_bf16x3(B, K)
+    side = torch.cuda.Stream(priority=-1)
+    saved = me.GEMM_MODE
+    try:
+        for mode in ("f32", "bf16x3"):
+            me.GEMM_MODE = mode
+            me._PLANES_BY_PTR[B.data_ptr()] = planes
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                ref = rasterize_meshes(xy_d, z_d, f_d, H, W).pix_to_face.clone()
+            torch.cuda.synchronize()
+            assert int((ref >= 0).sum()) > 100000
+            bad = torch.zeros((), dtype=torch.int64, device=DEV)
+            for _ in range(150):
+                for _ in range(3):
+                    me._gemm_nt(A, K, B, K, C, N, M, N, K, bias, 1, me.ACT_NONE, me.EPI_FWD)
+                with torch.cuda.stream(side):
+                    bad += (rasterize_meshes(xy_d, z_d, f_d, H, W).pix_to_face != ref).sum()
+            torch.cuda.synchronize()
+            assert int(bad) == 0, (mode, int(bad))
+    finally:
+        me.GEMM_MODE = saved
+        me._PLANES_BY_PTR.pop(B.data_ptr(), None)
