@@ -41,6 +41,24 @@ __global__ __launch_bounds__(256) void k_bf16(float* out, int iters, float av, f
   if (s == 123.456f) out[0] = s;
 }
 
+// the gfx90a-generation bf16 instruction (64-bit operands, k = 8 per issue): the one that does NOT disturb neighbouring kernels
+typedef short short4v __attribute__((ext_vector_type(4)));
+template <int NACC>
+__global__ __launch_bounds__(256) void k_bf16_1k(float* out, int iters, float av, float bv) {
+  f32x16 acc[NACC];
+  for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = (float)(threadIdx.x + i + r);
+  const short4v a = {(short)(0x3c00 + (int)av), 0x3c10, 0x3c20, 0x3c30}, b = {0x3d00, (short)(0x3d10 + (int)bv), 0x3d20, 0x3d30};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 123.456f) out[0] = s;
+}
+
 template <class K>
 static void run(const char* name, K kernel, double flop_per_mfma, int nacc, int wg_per_cu, double seconds) {
   int cus = 0;
@@ -67,5 +85,7 @@ int main(int argc, char** argv) {
   run("fp32  v_mfma_f32_32x32x2_f32", k_f32<4>, 32.0 * 32 * 2 * 2, 4, 2, secs);
   run("bf16  v_mfma_f32_32x32x16_bf16", k_bf16<4>, 32.0 * 32 * 16 * 2, 4, 1, secs);
   run("bf16  v_mfma_f32_32x32x16_bf16", k_bf16<4>, 32.0 * 32 * 16 * 2, 4, 2, secs);
+  run("bf16  v_mfma_f32_32x32x8_bf16_1k", k_bf16_1k<4>, 32.0 * 32 * 8 * 2, 4, 1, secs);
+  run("bf16  v_mfma_f32_32x32x8_bf16_1k", k_bf16_1k<4>, 32.0 * 32 * 8 * 2, 4, 2, secs);
   return 0;
 }

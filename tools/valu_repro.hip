@@ -203,6 +203,13 @@ __global__ __launch_bounds__(256) void agg_loads(const float* __restrict__ src_f
   for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (float)(threadIdx.x + i)); b[i] = (__bf16)(0.002f * (float)(threadIdx.x ^ i)); }
   const float af = 0.001f * (float)threadIdx.x, bf = 0.002f * (float)(threadIdx.x ^ 5);
   f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+  typedef short short4v __attribute__((ext_vector_type(4)));
+  f32x4v d0 = {}, d1 = {}, d2 = {}, d3 = {};
+  half8 ha, hb;
+  for (int i = 0; i < 8; ++i) { ha[i] = (_Float16)(0.001f * (float)(threadIdx.x + i)); hb[i] = (_Float16)(0.002f * (float)(threadIdx.x ^ i)); }
+  const short4v sa = {(short)(0x3c00 + threadIdx.x), 0x3c10, 0x3c20, 0x3c30}, sb = {0x3d00, (short)(0x3d10 + threadIdx.x), 0x3d20, 0x3d30};
   float acc = 0.f;
   load(st[0]); load(st[1]); load(st[2]);
   for (int i = 0; i < iters; i += 3) {
@@ -217,6 +224,24 @@ __global__ __launch_bounds__(256) void agg_loads(const float* __restrict__ src_f
           c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c1, 0, 0, 0);
           c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, c3, 0, 0, 0);
         }
+      } else if (KIND == 3) {                      // v_mfma_f32_16x16x32_bf16 (the other gfx950 bf16 shape), same flops per step
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+          d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, d0, 0, 0, 0); d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, d1, 0, 0, 0);
+          d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, a, d2, 0, 0, 0); d3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, b, d3, 0, 0, 0);
+        }
+      } else if (KIND == 4) {                      // v_mfma_f32_32x32x16_f16
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hb, ha, c1, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, ha, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hb, hb, c3, 0, 0, 0);
+        }
+      } else if (KIND == 5) {                      // v_mfma_f32_32x32x8_bf16_1k (the gfx90a-generation bf16 instruction: half the k per issue)
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+          c0 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(sa, sb, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(sb, sa, c1, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(sa, sa, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(sb, sb, c3, 0, 0, 0);
+        }
       } else if (KIND == 2) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -230,7 +255,7 @@ __global__ __launch_bounds__(256) void agg_loads(const float* __restrict__ src_f
   for (int s = 0; s < 3; ++s)
 #pragma unroll
     for (int j = 0; j < NL; ++j) acc += first_of(st[s][j]);
-  out[blockIdx.x * 256 + threadIdx.x] = acc + c0[0] + c1[1] + c2[2] + c3[3];
+  out[blockIdx.x * 256 + threadIdx.x] = acc + c0[0] + c1[1] + c2[2] + c3[3] + d0[0] + d1[1] + d2[2] + d3[3];
 }
 // the same stream with LDS as the destination of the loads (global_load_lds_dwordx4: no VGPR is written by a returning load) + the bf16 MFMAs
 __global__ __launch_bounds__(256) void agg_loads_lds(const float* __restrict__ src_f, long nfloat, float* out, int iters) {
@@ -275,7 +300,7 @@ extern "C" int valu_repro_neighbour_loads(int kind, int width, const float* src,
   hipStream_t st = (hipStream_t)stream;
   const dim3 g(2048), b(256);
 #define SR_AGG(W, K) hipLaunchKernelGGL((agg_loads<W, K>), g, b, 0, st, src, nfloat, out, iters)
-  if (width == 4) { if (kind == 0) SR_AGG(4, 0); else if (kind == 1) SR_AGG(4, 1); else SR_AGG(4, 2); }
+  if (width == 4) { if (kind == 0) SR_AGG(4, 0); else if (kind == 1) SR_AGG(4, 1); else if (kind == 2) SR_AGG(4, 2); else if (kind == 3) SR_AGG(4, 3); else if (kind == 4) SR_AGG(4, 4); else SR_AGG(4, 5); }
   else if (width == 2) { if (kind == 0) SR_AGG(2, 0); else if (kind == 1) SR_AGG(2, 1); else SR_AGG(2, 2); }
   else { if (kind == 0) SR_AGG(1, 0); else if (kind == 1) SR_AGG(1, 1); else SR_AGG(1, 2); }
 #undef SR_AGG

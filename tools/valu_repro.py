@@ -105,6 +105,12 @@ if os.environ.get("SR_VR_LOADS") == "1":
             rc = lib.valu_repro_neighbour_loads_lds(big.data_ptr(), big.numel(), nb_out.data_ptr(), iters, torch.cuda.current_stream().cuda_stream)
             assert rc == 0, rc
         return work
+    if os.environ.get("SR_VR_MFMA_KINDS") == "1":
+        arm("next to the 16-byte load stream + v_mfma_f32_16x16x32_bf16", loads(3, 4, 600))
+        arm("next to the 16-byte load stream + v_mfma_f32_32x32x16_f16", loads(4, 4, 600))
+        arm("next to the 16-byte load stream + v_mfma_f32_32x32x8_bf16_1k", loads(5, 4, 600))
+        arm("next to the 16-byte load stream + v_mfma_f32_32x32x16_bf16 (control)", loads(1, 4, 600))
+        sys.exit(0)
     if os.environ.get("SR_VR_LDS_ONLY") == "1":
         arm("next to the stream of 16-byte loads with LDS as their destination + the bf16 MFMAs", loads_lds(600))
         arm("next to that stream + 24 v_mfma_f32_32x32x16_bf16 per step (VGPR destination, control)", loads(1, 4, 600))
