@@ -33,7 +33,7 @@ At lr 1e-4 the refiner accepts 7-16 % of the rays between two remeshes: Adam's l
 60*mean|f(TmpVs)| keeps the seeds ~3e-3 off the zero set, 60x the acceptance threshold |f| < 5e-5 (profiles/r02_convergence.md).
 The reference's own run does the same: tests/test_trajectory_long_gpu.py holds the product's acceptance rate to the reference's
 (0.09 / 0.25 / 0.15 / 0.26 per 16 iterations of a 64-iteration run at lr 1e-4 with four remeshes).  At the late rate ~75 % converge.
-Other records of the default single-GPU run: `fine_stage`, `bf16x3` (opt-in split-bf16 layer GEMMs), `strong_scaling_model`
+Other records of the default single-GPU run: `fine_stage`, `strong_scaling_model`
 (configs[2]: 8 frames on one GPU against the workload of one rank of 8), `seg3d_mc_513` (configs[3]), `loose1080` (configs[4]).
 The timed window always contains exactly one remesh when K <= the remesh interval (for K = 20 that over-counts its share:
 1/20 instead of 1/30 or 1/120); its duration is reported, with the properly amortised figure beside.  The K timed steps run
@@ -56,6 +56,33 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 STAGES = {"coarse": dict(frames=3, rays=2048), "fine": dict(frames=1, rays=6144)}
+
+
+def gpu_sensors():
+    """Shader clock (MHz) and socket power (W) of the first amdgpu device from sysfs -- two small file reads, cheap enough to take INSIDE
+    the timed window while the GPU is loaded (rocm-smi is a Python process of its own: 0.3 s of host CPU per sample).  None where the
+    files do not exist (containers without /sys/class/drm)."""
+    import glob
+    out = {}
+    try:
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))[:1]:
+            for line in open(f):
+                if "*" in line:
+                    out["sclk_mhz"] = int("".join(c for c in line.split(":")[1] if c.isdigit()))
+            for name in ("power1_average", "power1_input"):
+                for h in glob.glob(os.path.join(os.path.dirname(f), "hwmon", "hwmon*", name)):
+                    out["power_w"] = round(int(open(h).read().strip()) / 1e6, 1)
+                    break
+                if "power_w" in out:
+                    break
+    except (OSError, ValueError, IndexError):
+        pass
+    return out or None
+
+
+def _eager_ray_branch():
+    from selfreconcode_amd.model import optim_network
+    return bool(optim_network.EAGER_RAY_BRANCH)
 
 
 def frames_per_rank(stage, args, world):
@@ -114,14 +141,27 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def timed(n):
+    diag = {}
+
+    def timed(n, sense=False):
+        """`sense`: also record what explains a box-to-box difference of the figure -- the shader clock / power half-way through and at
+        the end of the window (GPU loaded), and how long the final synchronisation waits after the host has issued the last step
+        (~0: the host is the bottleneck; several ms: the GPU is, the host runs ahead)."""
         conv.clear()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(n):
+        for i in range(n):
             step()
+            if sense and i == n // 2:
+                diag["sensors_mid_window"] = gpu_sensors()
+        t_issued = time.perf_counter()
+        if sense:
+            diag["sensors_end_of_window"] = gpu_sensors()
         barrier()
         el = time.perf_counter() - t0
+        if sense:
+            diag["host_issue_ms_per_step"] = round((t_issued - t0) / n * 1e3, 3)
+            diag["host_ahead_ms_at_the_end"] = round((t0 + el - t_issued) * 1e3, 3)
         t = torch.tensor([el], device=device, dtype=torch.float64)
         if srdist.is_distributed():
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -159,7 +199,7 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
     # costs 2-6 ms of it: every hipEventRecord is a marker packet the command processor has to retire between two kernels).
     net.remesh_events = net.refiner_events = None
     mlp_engine.PROFILE.reset(enabled=False)
-    el, rays, cf = timed(steps)
+    el, rays, cf = timed(steps, sense=True)
     # Pass 2 -- the same K steps again with the HIP-event pairs (roofline leg, per-shape table), the remesh and refiner events
     prof, shapes, rem, refiner_ms, el_i = {}, None, [], None, None
     net.refiner_stream = "main"          # instrumented pass: one stream of GEMMs, so that an event interval is a kernel's own duration
@@ -206,7 +246,7 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
                                                                         "interval": Rm},
                 "ms_per_step_remesh_amortised": None if rem_each is None else round((el * 1e3 - rem_each) / steps + rem_each / Rm, 3),
                 "refiner_ms_per_step": None if refiner_ms is None else round(refiner_ms, 3),
-                "frames_per_gpu": FR, "rays_per_frame": RAYS, "image": [ds.H, ds.W], "lr_timed": timed_lr, "prof": prof, "shapes": shapes, "net": net})
+                "diagnostics": diag, "frames_per_gpu": FR, "rays_per_frame": RAYS, "image": [ds.H, ds.W], "lr_timed": timed_lr, "prof": prof, "shapes": shapes, "net": net})
     return rec
 
 
@@ -325,8 +365,6 @@ def main():
     ap.add_argument("--refiner-impl", choices=["device", "layerwise"], default="device", help="device-driven compacting refiner or the layer-by-layer host loop")
     ap.add_argument("--no-sdf-throughput", action="store_true", help="skip the SDF-MLP Gsamples/s leg (PMC passes: keeps the launch population = the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gemm", choices=["f32", "bf16x3"], default="f32", help="arithmetic of the large forward / backward-data layer GEMMs of the HEADLINE run (default: exact fp32 MFMA)")
-    ap.add_argument("--no-bf16x3-record", action="store_true", help="skip the secondary record with the split-bf16 layer GEMMs")
     ap.add_argument("--no-extra-records", action="store_true", help="skip the late-rate, configs[3] (Seg3d + MC at 513^3), configs[4] (1080 x 1080, config_loose.conf) and strong-scaling-model records")
     ap.add_argument("--simulate-world", type=int, default=0, help="N=1 only: time the workload ONE rank of this many would run (the replicated template term evaluated on 1/R of the vertices, no collectives)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam (multi-tensor launches) instead of the one-launch FusedAdam")
@@ -346,8 +384,6 @@ def main():
             raise SystemExit("--simulate-world is a single-GPU measurement")
         srdist.simulate_world((0, args.simulate_world))
 
-    from selfreconcode_amd import mlp_engine as _me
-    _me.set_gemm_mode(args.gemm)
     # The learning rate of a record is the one config.conf runs that stage at: the coarse stage is epochs 0-5, all at 1e-4
     # (config.conf:16-34); the fine stage starts at epoch 12 and spends epochs 80-129 at 1e-4 * 0.333^3 (the MultiStepLR milestones).
     lr_of = lambda stage: args.lr if args.lr is not None else (None if stage == "coarse" else args.late_lr)
@@ -385,22 +421,6 @@ def main():
     if world == 1 and args.stage == "coarse" and not args.no_fine and args.scaling == "weak" and not args.frames_per_gpu and not args.simulate_world:
         fine_rec = strip(run_stage("fine", args, rank, world, device, args.steps, args.warmup, max(args.settle // 2, 0), args.settle_low, False, timed_lr=lr_of("fine")))
         fine_rec["workload"] = "fine stage (1 frame x 6144 rays, 321x417x225 grid, remesh every 120: config.conf:39-48,113) at the MultiStepLR rate of epochs 80-129"
-
-    # secondary record: the same workload with the split-bf16 (three bf16 terms per operand, six products, fp32 accumulation) forward /
-    # backward-data layer GEMMs -- fp32-equivalent accuracy on the bf16 MFMA pipe; opt-in (SR_GEMM=bf16x3), never the headline
-    bf16x3_rec = None
-    if world == 1 and args.gemm == "f32" and not args.no_bf16x3_record and not args.simulate_world:
-        _me.set_gemm_mode("bf16x3")
-        try:
-            r = strip(run_stage(args.stage, args, rank, world, device, min(args.steps, 20), args.warmup, max(args.settle // 2, 0), args.settle_low, False, timed_lr=lr_of(args.stage)))
-        finally:
-            _me.set_gemm_mode("f32")
-        bf16x3_rec = {"dtype": "f32-emulated-bf16x3", "ms_per_step": r["ms_per_step"], "iterations_per_s": round(1e3 / r["ms_per_step"], 4),
-                      "rays_converged_frac": r["rays_converged_frac"], "ms_per_step_remesh_amortised": r["ms_per_step_remesh_amortised"],
-                      "what": "forward / backward-data layer GEMMs with >= 8192 rows: operands split into three bf16 terms, six products accumulated in fp32 by "
-                              "v_mfma_f32_32x32x16_bf16 (error below the fp32 MFMA kernel's, tests/test_mlp_gpu.py); refiner chains, weight-gradient GEMMs and "
-                              "small launches stay exact fp32; 256 x 256 workgroup tiles (the CU-owning tiling: reproducible next to the other streams' kernels, "
-                              "DESIGN.md 3.1; the 128 x 128 tiling of SR_BF16X3_TILE=128 is ~1.7 ms faster inside the iteration and is not)"}
 
     # configs[2] (8 frames over 8 GPUs) cannot be run on one GPU; what CAN be measured here is both ends of its strong-scaling
     # ratio: the whole 8-frame step on one GPU, and the step ONE rank of 8 would run (1 frame, the replicated template term on 1/8 of
@@ -445,7 +465,7 @@ def main():
         "metric": f"train.py-equivalent iterations/sec (540x540, {RAYS} rays/frame x {FR} frame{'s' if FR > 1 else ''} per GPU; {args.stage} stage at Adam lr {lr_timed:.3g})",
         "value": round(args.steps * world * FR / FR_REF / elapsed, 4), "unit": "iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_rec["ms_per_step"],
-        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32" if args.gemm == "f32" else "f32-emulated-bf16x3", "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[1]: female-3-casual-like 540x540, {args.stage} stage = {epochs}, Adam lr {lr_timed:.3g}, {FR} frame(s) x {RAYS} rays per rank, full iteration "
                                "(template deform + K=50 point-silhouette mask loss + template SGD, mesh rasteriser + seeds + Newton refiner, "
                                "eikonal/offset/def-regu/DCT/colour/normal, backward, implicit-grad propagation, Adam, one remesh in the timed window)"
@@ -459,6 +479,8 @@ def main():
                    "rays_per_iter": main_rec["rays_per_iter"], "rays_converged_frac": main_rec["rays_converged_frac"],
                    "observations": "uniform noise" if args.noise_observations else "rendered from the scene (render_frames), re-rendered after the settle phase",
                    "refiner": {"impl": args.refiner_impl, "stream_headline_pass": args.refiner_stream, "stream_instrumented_pass": "main"},
+                   "ray_branch": ("colour / normal terms back-propagated inside forward() and the implicit-gradient pass, both on the side stream under the sampled terms and "
+                                  "their backward (headline pass); main stream in the instrumented pass") if _eager_ray_branch() else "one backward of the total loss (SR_EAGER_RAY_BRANCH=0)",
                    "optimizer": {"impl": "torch.optim.Adam" if args.torch_adam else "FusedAdam (same update rule, one launch)", "lr_timed": lr_timed, "settle_iters_lr_1e-4": args.settle,
                                  "settle_iters_lr_timed": args.settle_low if lr_timed != 1e-4 else 0},
                    "rasterisation": "in-repo HIP kernels with pytorch3d 0.4.0 semantics (nearest-face mesh rasteriser -> FindSurfacePs; K=50 nearest-in-z "
@@ -469,10 +491,12 @@ def main():
         "remesh": main_rec["remesh"], "ms_per_step_remesh_amortised": main_rec["ms_per_step_remesh_amortised"],
         "ms_per_step_instrumented": main_rec["ms_per_step_instrumented"],
         "refiner_ms_per_step": main_rec["refiner_ms_per_step"],
+        "diagnostics": dict(main_rec["diagnostics"], note="taken inside the headline window: shader clock / socket power from sysfs half-way through and after the last step was "
+                                                          "issued; host_issue_ms_per_step = host time to enqueue a step, host_ahead_ms_at_the_end = how long the final synchronisation waited "
+                                                          "(~0 means the host paces the step)"),
         "regime_lr_config": main_rec.get("regime_lr_config"),
         "late_schedule_lr": main_rec.get("late_schedule_lr"),
         "fine_stage": fine_rec,
-        "bf16x3": bf16x3_rec,
         "strong_scaling_model": strong_rec,
         "seg3d_mc_513": seg_rec,
         "loose1080": loose_rec,

@@ -123,15 +123,8 @@ typedef struct {
   int32_t naux_fwd;       /* FWD: number of filler columns appended after N */
   int32_t nact_bwd;       /* BWD: leading columns that go through the activation derivative */
   float aux_scale;        /* BWD: scale the stored activations carry */
-  /* Optional (NULL = exact-fp32 MFMA path): B pre-split into three bf16 planes, B = B3[0] + B3[1] + B3[2] to 2^-24 (sr_split_bf16x3),
-   * plane p at B3 + p * plane3, rows of ldb3 elements (multiple of 16, zero padded past K).  Large launches then run the split-bf16
-   * kernel: A is split the same way on the fly and the six leading products are accumulated in fp32 on the bf16 MFMA pipe. */
-  const uint16_t* B3; int64_t ldb3; int64_t plane3;
 } sr_gemm_args;
 int sr_mlp_gemm_nt(const sr_gemm_args* host_args, void* stream);
-/* dst plane p [rows, ld_dst] (p = 0,1,2; planes `plane_stride` elements apart; ld_dst a multiple of 16 >= cols, padding written as 0):
- * x = bf16(x) + bf16(x - hi) + bf16(x - hi - mid), every conversion round-to-nearest-even.  The sum reproduces x to 2^-24 relative. */
-int sr_split_bf16x3(const float* src, int64_t ld_src, int64_t rows, int32_t cols, uint16_t* dst, int64_t ld_dst, int64_t plane_stride, void* stream);
 
 /* Layer chain: up to SR_CHAIN_MAX_LAYERS consecutive layer GEMMs of one or two independent networks (layer l of both side
  * by side in one grid) on a row count read from DEVICE memory: rows = *m_dev * m_mul <= m_cap * m_mul (every g[l][p].M is

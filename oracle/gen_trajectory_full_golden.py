@@ -1,0 +1,198 @@
+"""TEST INFRASTRUCTURE ONLY -- K = 32 consecutive training iterations of the REFERENCE AT THE SIZE BASELINE.json configs[1] IS QUOTED ON,
+with one remesh on the shipped coarse grid, run verbatim on CPU and frozen into tests/golden/trajectory_full.npz (build container only:
+needs /root/reference; ~25 s per iteration on 8 cores):
+
+    python oracle/gen_trajectory_full_golden.py [--k K]
+
+This is the quality pin SURVEY.md's north_star asks for ("matching silhouette IoU after equal iterations"): the reference's only
+quantitative quality metric is the mask error 1 - IoU of the rasterised deformed template against the ground-truth mask
+(infer.py:172-181, computed model/network.py:322-324).  The loop is train.py:147-170 -- `optimizer.zero_grad(); loss = optNet(...);
+loss.backward(); optNet.propagateTmpPsGrad(...); optimizer.step()` -- with Adam(lr 1e-4: the rate config.conf runs the coarse stage at)
+over the dataset's learnable tensors and the three networks, the template's SGD inside forward, on the scene of
+oracle/gen_fullsize_golden.py's coarse stage: 540 x 540, 3 frames x 2048 rays per iteration, the real 65 x 225 x 129 skinning-weight
+volume, a template of 84 968 vertices, loss_coarse.  At the call with index REMESH_AT `forward_time % remesh_intersect == 0`
+(network.py:463-478): the reference's own Seg3dLossless (MCAcc/seg3d_lossless.py, CPU) on the coarse pyramid of train.py:29-37
+(15 x 21 x 9 ... 225 x 321 x 129) + the reference's own marching-cubes kernels (oracle/_ref/libmc_ref_fma.so) behind `MCGpu.mc_gpu`.
+Harness as oracle/gen_iteration_golden.py (pytorch3d renderers -> oracle/raster_oracle.py, CUDA extensions / torch_scatter -> their
+pinned restatements).  Draw c of iteration k is det_tensor / det_normal with seed DRAW_BASE + 16 k + c, so the product regenerates them.
+
+Stored per iteration: every loss term and the total, rayInfo (rays selected, rays the refiner accepted), the template's vertex count,
+and -- the quality metric -- the mask error 1 - IoU of EVERY frame of the batch (from the fragments the mesh rasteriser stand-in hands
+`forward`: the same silhouette `infer` rasterises); at the remesh the vertex / face counts and a strided vertex sample; at the end maskE
+of `infer` on EVAL_FRAMES and parameter digests.
+"""
+import os
+import sys
+import time
+import types
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import gen_iteration_golden as gi  # noqa: E402
+from oracle import gen_fullsize_golden as gf  # noqa: E402
+from oracle import gen_trajectory_golden as gt  # noqa: E402
+from oracle import fixtures as fx  # noqa: E402
+from oracle import raster_oracle as ro  # noqa: E402
+from oracle import mc as mco  # noqa: E402
+
+ref = gi.ref
+OUT = os.path.join(ROOT, "tests", "golden")
+K, REMESH_AT = 32, 12
+LR = 1e-4
+DRAW_BASE = 29000
+EVAL_FRAMES = [2, 11, 19, 30]
+RES_COARSE = [(15, 21, 9), (29, 41, 17), (57, 81, 33), (113, 161, 65), (225, 321, 129)]       # train.py:29-37
+
+
+def frames_of(k, F):
+    return [(7 + 3 * k) % F, (21 + 5 * k) % F, (30 + 7 * k) % F]
+
+
+def ratio_of(k):
+    return {'sdfRatio': 1., 'deformerRatio': k / 2500. + 0.5, 'renderRatio': 1.}
+
+
+_OBS = {}
+
+
+def observations(fids, H, W):
+    """Per-frame observations keyed by the GLOBAL frame id (both sides rebuild them): noise colours / normals, the fixed elliptic mask."""
+    imgs, nrms = [], []
+    for f in fids:
+        f = int(f)
+        if f not in _OBS:
+            n = fx.det_tensor((H, W, 3), 9200 + f, 1.0)
+            n[::5] = 0.
+            _OBS[f] = (fx.det_tensor((H, W, 3), 9100 + f, 1.0), n)
+        imgs.append(_OBS[f][0]); nrms.append(_OBS[f][1])
+    return {'img': torch.stack(imgs), 'mask': gf.mask_image(len(fids), H, W), 'normal': torch.stack(nrms)}
+
+
+class Draws(gt.Draws):
+    def rand(self, *size, **kw):
+        shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+        self.calls.append(('rand', shape))
+        return fx.det_tensor(shape, DRAW_BASE + 16 * self.k + len(self.calls) - 1, 0.5) + 0.5
+
+    def randn_like(self, x, **kw):
+        self.calls.append(('randn_like', tuple(x.shape)))
+        return fx.det_normal(tuple(x.shape), DRAW_BASE + 16 * self.k + len(self.calls) - 1)
+
+
+class MaskRender(gt.MaskRender):
+    """as the trajectory harness's (topology of the mesh it is handed), and keeps the last fragments: their coverage is the silhouette
+    whose IoU error against the ground-truth mask is the reference's quality metric (network.py:322-324)."""
+
+    def __call__(self, meshes):
+        out = super().__call__(meshes)
+        self.last_p2f = out[1].pix_to_face
+        return out
+
+
+def mask_error(masks, gtm):
+    n = masks.shape[0]
+    return 1. - (masks * gtm).view(n, -1).sum(1) / (masks + gtm - masks * gtm).abs().view(n, -1).sum(1)
+
+
+def main():
+    kk = K
+    if "--k" in sys.argv:
+        kk = int(sys.argv[sys.argv.index("--k") + 1])
+    torch.set_num_threads(os.cpu_count())
+    t_start = time.perf_counter()
+    net, ds, _, _, q, V0, faces = gf.build("coarse")
+    H = W = 540
+    F = ds.frame_num
+    N = 3
+    net.maskRender = MaskRender(H, W, faces)
+    net.engine = ref.MCAcc.Seg3dLossless(query_func=None, b_min=fx.LBS_BMIN, b_max=fx.LBS_BMAX, resolutions=RES_COARSE, align_corners=False, balance_value=0.0,
+                                         device='cpu', visualize=False, debug=False, use_cuda_impl=False, faster=False)
+    remeshed = {}
+
+    def mc_gpu(sdfs, xs, ys, zs, x0, y0, z0, iso):                       # MCGpu.mc_gpu (MCGpu/MCGpu.cpp:20-56) through the reference's kernels
+        t0 = time.perf_counter()
+        v, keys, f = mco.reference_marching_cubes(sdfs.numpy(), (float(xs), float(ys), float(zs)), (float(x0), float(y0), float(z0)), float(iso), mode="fma")
+        v, keys, f = mco.canonical(v, keys, f)
+        remeshed['V'], remeshed['F'] = torch.from_numpy(v.copy()), torch.from_numpy(f.copy())
+        print(f"    marching cubes (reference kernels, host build): {time.perf_counter() - t0:.1f} s, V = {v.shape[0]}, F = {f.shape[0]}", flush=True)
+        return [remeshed['V'].clone(), remeshed['F'].clone()]
+    ref.network.MCGpu = types.SimpleNamespace(mc_gpu=mc_gpu)
+
+    class _TriMesh:                                                      # openmesh.TriMesh: network.py:472-478 builds vertex->face tables nobody reads
+        def __init__(self, v, f):
+            self.n = len(v)
+
+        def vertex_face_indices(self):
+            return -np.ones((self.n, 1), np.int64)
+    ref.network.om = types.SimpleNamespace(TriMesh=_TriMesh)
+    net.forward_time, net.remesh_intersect, net.remesh_time = 30 - REMESH_AT, 30, 0.          # one remesh in the window: at the call with index REMESH_AT
+    learn = [ds.conds[0], ds.conds[1], ds.focal, ds.princ, ds.T, ds.poses, ds.trans]          # dataset.learnable_weights(): codes, camera, poses, trans
+    optimizer = torch.optim.Adam([{'params': learn}, {'params': [p for p in net.parameters() if p.requires_grad]}], lr=LR)
+    gtm1 = gf.mask_image(1, H, W)
+
+    real_rand, real_randn_like = torch.rand, torch.randn_like
+    out = dict(q=q.view(-1), HW=np.array([H, W]), SP=np.array(2048), K=np.array(kk), remesh_at=np.array(REMESH_AT), frame_num=np.array(F), lr=np.array(LR),
+               radius=np.array(0.006), ang_thr=np.array(net.angThred), res=np.array(RES_COARSE), eval_frames=np.array(EVAL_FRAMES), lbs_shape=np.array([65, 225, 129]),
+               n_cube=np.array(gf.STAGES["coarse"]["n_cube"]), draw_base=np.array(DRAW_BASE))
+    names = ('grad_loss', 'def_loss', 'dct_loss', 'color_loss', 'normal_loss', 'offset_loss', 'pc_loss_sdf')
+    curve = {n: [] for n in names + ('mask_loss', 'defconst_loss', 'total')}
+    ray_counts, draw_shapes, vcount, maskE_it, seconds = [], [], [], [], []
+    for k in range(kk):
+        t0 = time.perf_counter()
+        fids = torch.tensor(frames_of(k, F))
+        draws = Draws(k)
+        torch.rand, torch.randn_like = draws.rand, draws.randn_like
+        try:
+            optimizer.zero_grad()
+            loss = net(observations(fids, H, W), 2048, ratio_of(k), fids)
+            loss.backward()
+            net.propagateTmpPsGrad(fids, ratio_of(k))
+            optimizer.step()
+        finally:
+            torch.rand, torch.randn_like = real_rand, real_randn_like
+        info = net.info
+        for n in names:
+            curve[n].append(float(info.get(n, float('nan'))) if not (n == 'color_loss' and float(info.get(n, -1.)) < 0) else float('nan'))
+        curve['mask_loss'].append(float(info['pc_loss']['mask_loss'])); curve['defconst_loss'].append(float(info['pc_loss']['defconst_loss']))
+        curve['total'].append(float(loss))
+        ray_counts.append([int(info['rayInfo'][0]), int(info['rayInfo'][1])])
+        draw_shapes.append([list(s) + [0] * (2 - len(s)) for _, s in draws.calls] + [[0, 0]] * (6 - len(draws.calls)))
+        vcount.append(net.TmpVs.shape[0])
+        cover = (net.maskRender.last_p2f[..., 0] >= 0).float()
+        maskE_it.append(mask_error(cover, gtm1.expand(N, H, W)).tolist())
+        if 'V' in remeshed and "remesh_V" not in out:
+            out["remesh_V"], out["remesh_nV"], out["remesh_nF"], out["remesh_k"] = remeshed['V'][::11].clone(), np.array(remeshed['V'].shape[0]), np.array(remeshed['F'].shape[0]), np.array(k)
+        seconds.append(time.perf_counter() - t0)
+        print(k, frames_of(k, F), "loss %.6f" % float(loss), "rays", info['rayInfo'], "V", net.TmpVs.shape[0], "maskE", np.round(maskE_it[-1], 4).tolist(),
+              "%.1f s" % seconds[-1], flush=True)
+    if kk > REMESH_AT:
+        assert "remesh_V" in out and int(out["remesh_k"]) == REMESH_AT
+    # ---- the end state: maskE of `infer` (network.py:306-324) on EVAL_FRAMES, parameter digests
+    with torch.no_grad():
+        ef = torch.tensor(EVAL_FRAMES)
+        poses, trans, dcond, _ = ds.get_grad_parameters(ef, 'cpu')
+        defV = net.deformer(net.TmpVs.detach()[None].expand(len(EVAL_FRAMES), -1, 3), [dcond, [poses, trans]], ratio=ratio_of(kk))
+        xy, z = ro.ndc_projection(defV, ds.focal.detach(), ds.princ.detach(), ds.R[0], ds.T.detach(), W, H)
+        p2f, _, _ = ro.rasterize_meshes(torch.cat([xy, z[..., None]], -1).float().numpy(), net.Tmpfs.numpy(), H, W)
+        masks = torch.from_numpy((p2f >= 0)[..., 0]).float()
+        maskE = mask_error(masks, gtm1.expand(len(EVAL_FRAMES), H, W))
+    out.update(maskE=maskE, maskE_it=np.array(maskE_it), ray_counts=np.array(ray_counts), draw_shapes=np.array(draw_shapes), vcount=np.array(vcount),
+               seconds_per_iteration=np.array(seconds), cores=np.array(os.cpu_count()),
+               **{"L_" + n: np.array(v) for n, v in curve.items()})
+    for tag, mod in (("sdf", net.sdf), ("tr", net.deformer.defs[0]), ("rn", net.netRender)):
+        for i, (name, p) in enumerate(mod.named_parameters()):
+            out[f"d_{tag}.{name}"] = gf.param_digest(p, 100 * i)
+    out["final_cam"] = torch.cat([ds.focal.detach(), ds.princ.detach(), ds.T.detach()])
+    conv = {k_: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k_, v in out.items()}
+    name = "trajectory_full.npz" if kk == K else f"trajectory_full_k{kk}.npz"
+    np.savez_compressed(os.path.join(OUT, name), **conv)
+    rc = np.array(ray_counts, dtype=np.float64)
+    print("wrote", name, os.path.getsize(os.path.join(OUT, name)), "bytes; total %.0f s; maskE" % (time.perf_counter() - t_start), maskE.tolist())
+    print("converged fraction per 8 iterations:", [round(float(rc[a:a + 8, 1].sum() / rc[a:a + 8, 0].sum()), 3) for a in range(0, kk, 8)])
+
+
+if __name__ == "__main__":
+    main()

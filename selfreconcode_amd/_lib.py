@@ -22,7 +22,7 @@ class SrGemmArgs(ctypes.Structure):
                 ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("bias", _vp),
                 ("group", ctypes.c_int32), ("act", ctypes.c_int32), ("mode", ctypes.c_int32), ("out_scale", ctypes.c_float),
                 ("aux", _vp), ("ldaux", _i64), ("naux_fwd", ctypes.c_int32), ("nact_bwd", ctypes.c_int32),
-                ("aux_scale", ctypes.c_float), ("B3", _vp), ("ldb3", _i64), ("plane3", _i64)]
+                ("aux_scale", ctypes.c_float)]
 
 
 class SrGemmTnArgs(ctypes.Structure):
@@ -153,7 +153,6 @@ SIGNATURES = {
     "sr_gridsample3d_dbwd_f32": [_vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _vp, _vp],
     "sr_gridsample3d_dbwd_f64": [_vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _T5, _vp, _vp, _vp],
     "sr_mlp_gemm_nt": [_vp, _vp],
-    "sr_split_bf16x3": [_vp, _i64, _i64, ctypes.c_int32, _vp, _i64, _i64, _vp],
     "sr_mlp_chain": [_vp, _vp],
     "sr_refine_init": [_vp, _vp],
     "sr_refine_embed": [_vp, ctypes.c_int32, _vp],

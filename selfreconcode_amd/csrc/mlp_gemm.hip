@@ -429,493 +429,6 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
 // 262144 x 512 x 512: retiring a workgroup and placing a fresh one is not where the time goes.)
 
 // ------------------------------------------------------------------------------------------------
-// Split-bf16 ("bf16x3") form of the same tile, opt-in (sr_gemm_args::B3): every fp32 operand is written as the sum of three bf16
-// numbers  x = x1 + x2 + x3  (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 3 x 8 mantissa bits, exact to 2^-24) and the six
-// leading products  a1 b1 + a1 b2 + a2 b1 + a1 b3 + a3 b1 + a2 b2  are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 -- the dropped
-// terms are below 2^-24 of |a||b|, so a dot product is as accurate as the fp32 MFMA's (measured: better, the partial products are
-// exact), at 6/16 of its MFMA time: the bf16 pipe runs 16x the fp32 rate (2.46 PFLOP/s measured on this part, tools/mfma_peak.hip).
-// B (a weight matrix) arrives pre-split (three bf16 planes, sr_split_bf16x3, once per optimizer step); A (activations / cotangents) is
-// split by the thread that stages it, on its way from registers to LDS.  LDS holds bf16 planes [row][16 + 8] (48-byte pitch: the 16
-// lanes of a ds_read_b128 group hit 16 distinct 16-byte slots); a lane's fragment is 8 consecutive k of its row = one 16-byte read per
-// plane; BK = 16 per step, two LDS buffers, two register stages (tile t+2 in flight from global memory), one barrier per step in the
-// middle of the MFMA stream -- the structure of the fp32 loop above.  The accumulator layout of the 32x32 MFMAs does not depend on
-// the input type, so the epilogues are the ones above, unchanged.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int BK3 = 16;           // k per step
-constexpr int P3 = BK3 + 8;       // LDS row pitch in bf16 elements (48 bytes)
-
-template <int WM, int WN, int TM, int TN>
-struct Cfg3 {
-  static constexpr int kThreads = WM * WN * 64;
-  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  static constexpr int kPlaneA = BM * P3, kPlaneB = BN * P3;                 // elements
-  static constexpr int kBufElems = 3 * (kPlaneA + kPlaneB);
-  static constexpr int kOperandBytes = 2 * kBufElems * 2;
-  static constexpr int kStageBytes = WM * WN * TM * 32 * (TN * 32 + 4) * 4;
-  static constexpr int kLdsBytes = kOperandBytes > kStageBytes ? kOperandBytes : kStageBytes;
-  static constexpr int kALoads = BM * (BK3 / 4) / kThreads;                   // float4 per thread and step
-  static_assert(BN * 2 == kThreads, "one 16-byte load per thread and plane");
-};
-
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned int bf16_bits(float x) { return (unsigned int)__builtin_bit_cast(unsigned short, (__bf16)x); }
-// x -> (hi, mid, lo) bf16 bit patterns, round-to-nearest-even at every step
-__device__ __forceinline__ void split_bf16x3(float x, unsigned int& h, unsigned int& m, unsigned int& l) {
-  h = bf16_bits(x);
-  const float r1 = x - __builtin_bit_cast(float, h << 16);
-  m = bf16_bits(r1);
-  const float r2 = r1 - __builtin_bit_cast(float, m << 16);
-  l = bf16_bits(r2);
-}
-// The same for a PAIR of values, as packed dwords (low half = first value): one v_cvt_pk_bf16_f32 per plane, the packed result is what goes
-// to LDS, and its two halves are turned back into floats with a shift and a mask -- 11 VALU operations per pair.
-__device__ __forceinline__ unsigned int cvt_pk_bf16(float a, float b) {
-  return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
-}
-__device__ __forceinline__ void split_pair_bf16x3(float a, float b, unsigned int& h, unsigned int& m, unsigned int& l) {
-  h = cvt_pk_bf16(a, b);
-  const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
-  m = cvt_pk_bf16(ra, rb);
-  l = cvt_pk_bf16(ra - __builtin_bit_cast(float, m << 16), rb - __builtin_bit_cast(float, m & 0xffff0000u));
-}
-
-template <int WM, int WN, int TM, int TN, bool KTAIL>
-__device__ __forceinline__ void gemm_nt_tile_bf16x3(const sr_gemm_args& g, int wg, unsigned char* __restrict__ smem_raw) {
-  using C_ = Cfg3<WM, WN, TM, TN>;
-  unsigned short* lds = reinterpret_cast<unsigned short*>(smem_raw);
-  auto Ap = [&](int buf, int p) -> unsigned short* { return lds + buf * C_::kBufElems + p * C_::kPlaneA; };
-  auto Bp = [&](int buf, int p) -> unsigned short* { return lds + buf * C_::kBufElems + 3 * C_::kPlaneA + p * C_::kPlaneB; };
-
-  const int tiles_n = (g.N + g.naux_fwd + C_::BN - 1) / C_::BN;
-  const int tiles_m = (g.M + C_::BM - 1) / C_::BM;
-  const int nwg = tiles_m * tiles_n;
-  {
-    const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, loc = wg / 8;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  const int tn = wg % tiles_n, tm = wg / tiles_n;
-  const int m0 = tm * C_::BM, n0 = tn * C_::BN;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int li = lane & 31, kh = lane >> 5;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  // ---- loaders.  A: fp32 rows (clamped into the matrix), 4 float4 per row and step.  B: one 16-byte run of a plane per thread.
-  const int nk = (g.K + BK3 - 1) / BK3;
-  // Thread -> (row, float4) maps chosen for the LDS stores (48-byte row pitch = 12 dwords, period 8 rows over the 32 store banks): the 16
-  // lanes of a ds_write_b64 group cover 8 rows x 2 adjacent float4 (8 x 4 dwords = 32 distinct banks), the 8 lanes of a ds_write_b128
-  // group 8 rows of one half (8 x 4 dwords).  (Rows x 4 float4 per 16 lanes, the natural map, is a 2-way conflict on a quarter of the
-  // banks: SQ_LDS_BANK_CONFLICT was a third of the LDS-active cycles.)
-  auto a_slot = [](int idx, int& row, int& kq) {                            // idx in [0, BM * 4)
-    const int u = idx >> 4;
-    row = ((u >> 1) << 3) | ((idx >> 1) & 7);
-    kq = (((u & 1) << 1) | (idx & 1)) * 4;
-  };
-  int arow[C_::kALoads], akq[C_::kALoads];
-  const int akmax = ((g.K + 3) & ~3) - 4;
-  const float* ap[C_::kALoads];
-#pragma unroll
-  for (int j = 0; j < C_::kALoads; ++j) {
-    a_slot(threadIdx.x + j * C_::kThreads, arow[j], akq[j]);
-    int gr = m0 + arow[j];
-    gr = gr < g.M ? gr : g.M - 1;
-    ap[j] = g.A + (int64_t)gr * g.lda;
-  }
-  const int brow_l = (threadIdx.x & 7) | ((threadIdx.x >> 4) << 3), bhalf = (threadIdx.x >> 3) & 1;
-  int brow = n0 + brow_l;
-  brow = brow < g.N ? brow : g.N - 1;
-  const unsigned short* bp = g.B3 + (int64_t)brow * g.ldb3 + bhalf * 8;
-  auto load = [&](int t, f32x4 (&ra)[C_::kALoads], u32x4 (&rb)[3]) {
-    const int tt = t < nk ? t : nk - 1;                                   // loads past the last step: clamped re-reads, never used
-#pragma unroll
-    for (int j = 0; j < C_::kALoads; ++j) {
-      const int gk = tt * BK3 + akq[j];
-      ra[j] = *reinterpret_cast<const f32x4*>(ap[j] + (gk < akmax ? gk : akmax));
-    }
-#pragma unroll
-    for (int p = 0; p < 3; ++p) rb[p] = *reinterpret_cast<const u32x4*>(bp + p * g.plane3 + (int64_t)tt * BK3);
-  };
-  auto store = [&](int buf, int t, const f32x4 (&ra)[C_::kALoads], const u32x4 (&rb)[3]) {
-#pragma unroll
-    for (int j = 0; j < C_::kALoads; ++j) {
-      f32x4 v = ra[j];
-      if (KTAIL) {                                                         // (K % 16 != 0 only: zero the floats of this float4 past K)
-        const int nvalid = g.K - (t * BK3 + akq[j]);
-        v.x = nvalid > 0 ? v.x : 0.f; v.y = nvalid > 1 ? v.y : 0.f; v.z = nvalid > 2 ? v.z : 0.f; v.w = nvalid > 3 ? v.w : 0.f;
-      }
-      unsigned int h0, m0_, l0, h1, m1, l1;
-      split_pair_bf16x3(v.x, v.y, h0, m0_, l0);
-      split_pair_bf16x3(v.z, v.w, h1, m1, l1);
-      const int off = arow[j] * P3 + akq[j];
-      *reinterpret_cast<u32x2*>(Ap(buf, 0) + off) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(Ap(buf, 1) + off) = u32x2{m0_, m1};
-      *reinterpret_cast<u32x2*>(Ap(buf, 2) + off) = u32x2{l0, l1};
-    }
-    const int boff = brow_l * P3 + bhalf * 8;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(Bp(buf, p) + boff) = rb[p];
-  };
-  // fragments of one step: 3 planes x TM (A) and 3 planes x TN (B), 16 bytes each
-  const int a_off = (wm * TM * 32 + li) * P3 + kh * 8, b_off = (wn * TN * 32 + li) * P3 + kh * 8;
-  auto read_frags = [&](int buf, bf16x8_t (&fa)[3][TM], bf16x8_t (&fb)[3][TN]) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-#pragma unroll
-      for (int a = 0; a < TM; ++a) fa[p][a] = *reinterpret_cast<const bf16x8_t*>(Ap(buf, p) + a_off + a * 32 * P3);
-#pragma unroll
-      for (int b = 0; b < TN; ++b) fb[p][b] = *reinterpret_cast<const bf16x8_t*>(Bp(buf, p) + b_off + b * 32 * P3);
-    }
-  };
-  // The six products, smallest first; consecutive MFMAs go to DIFFERENT accumulators (a dependent bf16 MFMA cannot issue back to back).
-  //   PA / PB: plane of A / B of product q
-  auto mfma_products = [&](const bf16x8_t (&fa)[3][TM], const bf16x8_t (&fb)[3][TN], int q0, int q1) {
-    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
-#pragma unroll
-    for (int q = q0; q < q1; ++q)
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]][a], fb[PB[q]][b], acc[a][b], 0, 0, 0);
-  };
-
-  // THREE register stages: a step is only ~1500 cycles long here (the fp32 loop's is ~8000), so a tile is requested three steps before
-  // its MFMAs and two before it is split and written to LDS -- one step was less than the loaded L2 latency and every step began
-  // with a wait for memory.  Stages rotate with period 3, LDS buffers and fragment sets with period 2: the loop is unrolled by 6.
-  f32x4 ra[3][C_::kALoads];
-  u32x4 rb[3][3];
-  bf16x8_t fa[2][3][TM], fb[2][3][TN];
-  load(0, ra[0], rb[0]);
-  load(1, ra[1], rb[1]);
-  load(2, ra[2], rb[2]);
-  store(0, 0, ra[0], rb[0]);
-  __syncthreads();
-  read_frags(0, fa[0], fb[0]);
-  // step t: request tile t+3 (into the stage tile t held), stage tile t+1 into the other LDS buffer, MFMAs of tile t with the barrier
-  // and the fragment reads of tile t+1 before the last third of them
-  auto step = [&](int t, f32x4 (&ain)[C_::kALoads], u32x4 (&bin)[3], const f32x4 (&aout)[C_::kALoads], const u32x4 (&bout)[3],
-                  const bf16x8_t (&fa_)[3][TM], const bf16x8_t (&fb_)[3][TN], bf16x8_t (&fan)[3][TM], bf16x8_t (&fbn)[3][TN]) {
-    const int cur = t & 1;
-    load(t + 3, ain, bin);
-    store(cur ^ 1, t + 1, aout, bout);
-    mfma_products(fa_, fb_, 0, 4);
-    // Issue order of the 4 * TM * TN MFMAs before the barrier: the global loads first (one per MFMA), then the splitting arithmetic
-    // (5 VALU operations per MFMA: what a 32-cycle MFMA hides) with the LDS stores as they become ready.
-    constexpr int kPre = 4 * TM * TN;
-#pragma unroll
-    for (int i = 0; i < kPre; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (i < C_::kALoads + 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-      if (i >= kPre - (3 * C_::kALoads + 3)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    read_frags(cur ^ 1, fan, fbn);
-    mfma_products(fa_, fb_, 4, 6);
-#pragma unroll
-    for (int i = 0; i < 2 * TM * TN; ++i) {                                 // the fragment reads of the next step between the last MFMAs
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, (3 * (TM + TN) + 2 * TM * TN - 1) / (2 * TM * TN), 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  for (int t0 = 0; t0 < nk; t0 += 6) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-      if (t0 + i < nk) step(t0 + i, ra[i % 3], rb[i % 3], ra[(i + 1) % 3], rb[(i + 1) % 3], fa[i % 2], fb[i % 2], fa[(i + 1) % 2], fb[(i + 1) % 2]);
-  }
-  __syncthreads();   // the epilogue reuses the operand buffers
-
-  float* stage = reinterpret_cast<float*>(smem_raw) + wave * (TM * 32 * (TN * 32 + 4));
-  const bool interior = m0 + C_::BM <= g.M && n0 + C_::BN <= (g.mode == SR_EPI_FWD ? g.N : (g.nact_bwd < g.N ? g.nact_bwd : g.N));
-  if (interior) {
-    if (g.mode == SR_EPI_FWD) {
-      switch (g.group) {
-        case 1: epilogue_interior_act<WM, WN, TM, TN, 1, SR_EPI_FWD>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
-        case 2: epilogue_interior_act<WM, WN, TM, TN, 2, SR_EPI_FWD>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
-        default: epilogue_interior_act<WM, WN, TM, TN, 4, SR_EPI_FWD>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
-      }
-    } else {
-      switch (g.group) {
-        case 1: epilogue_interior_act<WM, WN, TM, TN, 1, SR_EPI_BWD>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
-        case 2: epilogue_interior_act<WM, WN, TM, TN, 2, SR_EPI_BWD>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
-        default: epilogue_interior_act<WM, WN, TM, TN, 4, SR_EPI_BWD>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
-      }
-    }
-  } else {
-    switch (g.group) {
-      case 1: epilogue<WM, WN, TM, TN, 1>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
-      case 2: epilogue<WM, WN, TM, TN, 2>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
-      default: epilogue<WM, WN, TM, TN, 4>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
-    }
-  }
-}
-
-template <int WM, int WN, int TM, int TN, bool KTAIL>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_bf16x3_kernel(sr_gemm_args g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-  gemm_nt_tile_bf16x3<WM, WN, TM, TN, KTAIL>(g, blockIdx.x, smem3);
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same split-bf16 product with 128 x 128 WAVE tiles (256 x 256 per workgroup of 4 waves, one workgroup per CU): the 64 x 64 wave
-// tile above reads six fragment sets from LDS per 24 MFMAs and is LDS-bound (SQ counters: 3.5x the LDS activity per cycle of the fp32
-// kernel, a third of it bank conflicts); a 128 x 128 wave tile reads 24 fragments per 96 MFMAs -- half the LDS bytes per MFMA.  Its 256
-// accumulator registers live in the AGPR half of the unified register file (waves_per_eu(1): one wave per SIMD may use 512 registers), the
-// VGPR half holds two sets of A fragments, two half-sets of B fragments and ONE register stage of global data (a step is 96 MFMAs =
-// ~3000 cycles, longer than the loaded L2 latency).  Schedule of step t (LDS buffer t & 1 holds tile t):
-//   first half : MFMAs of the B blocks 0,1  |  fragments of B blocks 2,3 from LDS;  tile t+1: split, registers -> other LDS buffer
-//   barrier
-//   second half: MFMAs of the B blocks 2,3  |  tile t+2: global memory -> registers;  fragments of tile t+1 (A: other set, B blocks 0,1)
-// One barrier per 96 MFMAs; a wave never waits for an LDS read it has just issued.
-struct Cfg3W {
-  static constexpr int BM = 256, BN = 256;
-  static constexpr int kPlaneA = BM * P3, kPlaneB = BN * P3;                 // elements
-  static constexpr int kBufElems = 3 * (kPlaneA + kPlaneB);
-  static constexpr int kOperandBytes = 2 * kBufElems * 2;
-  static constexpr int kStageBytes = 4 * 32 * (4 * 32 + 4) * 4;              // epilogue: one 32-row band of a wave's tile at a time
-  static constexpr int kLdsBytes = kOperandBytes > kStageBytes ? kOperandBytes : kStageBytes;
-};
-
-template <bool KTAIL>
-__device__ __forceinline__ void gemm_nt_tile_bf16x3_w128(const sr_gemm_args& g, int wg, unsigned char* __restrict__ smem_raw) {
-  using C_ = Cfg3W;
-  unsigned short* lds = reinterpret_cast<unsigned short*>(smem_raw);
-  auto Ap = [&](int buf, int p) -> unsigned short* { return lds + buf * C_::kBufElems + p * C_::kPlaneA; };
-  auto Bp = [&](int buf, int p) -> unsigned short* { return lds + buf * C_::kBufElems + 3 * C_::kPlaneA + p * C_::kPlaneB; };
-  const int tiles_n = (g.N + g.naux_fwd + C_::BN - 1) / C_::BN;
-  const int tiles_m = (g.M + C_::BM - 1) / C_::BM;
-  const int nwg = tiles_m * tiles_n;
-  {
-    const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, loc = wg / 8;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  const int tn = wg % tiles_n, tm = wg / tiles_n;
-  const int m0 = tm * C_::BM, n0 = tn * C_::BN;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int li = lane & 31, kh = lane >> 5;
-
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  const int nk = (g.K + BK3 - 1) / BK3;
-  auto a_slot = [](int idx, int& row, int& kq) {                            // idx in [0, 256 * 4): the conflict-free store map of the 64 x 64 version
-    const int u = idx >> 4;
-    row = ((u >> 1) << 3) | ((idx >> 1) & 7);
-    kq = (((u & 1) << 1) | (idx & 1)) * 4;
-  };
-  int arow[4], akq[4];
-  const int akmax = ((g.K + 3) & ~3) - 4;
-  const float* ap[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    a_slot(threadIdx.x + j * 256, arow[j], akq[j]);
-    int gr = m0 + arow[j];
-    gr = gr < g.M ? gr : g.M - 1;
-    ap[j] = g.A + (int64_t)gr * g.lda;
-  }
-  const int brow_l = (threadIdx.x & 7) | ((threadIdx.x >> 4) << 3), bhalf = (threadIdx.x >> 3) & 1;     // rows 0..127; the second load: + 128
-  const unsigned short* bp[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int brow = n0 + brow_l + j * 128;
-    brow = brow < g.N ? brow : g.N - 1;
-    bp[j] = g.B3 + (int64_t)brow * g.ldb3 + bhalf * 8;
-  }
-  // ONE register stage of global data (a second one does not fit next to the fragments: the allocator spills and the kernel runs at 0.7
-  // of this form): tile t+1 is split and written to LDS at the very start of step t and the stage is re-requested with tile t+2 right
-  // behind it, so a load has almost a whole step (~90 MFMAs) to arrive.
-  f32x4 ra[4];
-  u32x4 rb[2][3];
-  auto load = [&](int t) {
-    const int tt = t < nk ? t : nk - 1;                                   // loads past the last step: clamped re-reads, never used
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gk = tt * BK3 + akq[j];
-      ra[j] = *reinterpret_cast<const f32x4*>(ap[j] + (gk < akmax ? gk : akmax));
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) rb[j][p] = *reinterpret_cast<const u32x4*>(bp[j] + p * g.plane3 + (int64_t)tt * BK3);
-  };
-  auto store = [&](int buf, int t) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 v = ra[j];
-      if (KTAIL) {
-        const int nvalid = g.K - (t * BK3 + akq[j]);
-        v.x = nvalid > 0 ? v.x : 0.f; v.y = nvalid > 1 ? v.y : 0.f; v.z = nvalid > 2 ? v.z : 0.f; v.w = nvalid > 3 ? v.w : 0.f;
-      }
-      unsigned int h0, m0_, l0, h1, m1, l1;
-      split_pair_bf16x3(v.x, v.y, h0, m0_, l0);
-      split_pair_bf16x3(v.z, v.w, h1, m1, l1);
-      const int off = arow[j] * P3 + akq[j];
-      *reinterpret_cast<u32x2*>(Ap(buf, 0) + off) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(Ap(buf, 1) + off) = u32x2{m0_, m1};
-      *reinterpret_cast<u32x2*>(Ap(buf, 2) + off) = u32x2{l0, l1};
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int boff = (brow_l + j * 128) * P3 + bhalf * 8;
-#pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(Bp(buf, p) + boff) = rb[j][p];
-    }
-  };
-  const int a_off = (wm * 128 + li) * P3 + kh * 8, b_off = (wn * 128 + li) * P3 + kh * 8;
-  // fragments of one PAIR of 32-row blocks (pair 0: blocks 0,1; pair 1: blocks 2,3), three planes
-  auto read_a = [&](int buf, int pair, bf16x8_t (&f)[3][2]) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) f[p][i] = *reinterpret_cast<const bf16x8_t*>(Ap(buf, p) + a_off + (pair * 2 + i) * 32 * P3);
-  };
-  auto read_b = [&](int buf, int pair, bf16x8_t (&f)[3][2]) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) f[p][i] = *reinterpret_cast<const bf16x8_t*>(Bp(buf, p) + b_off + (pair * 2 + i) * 32 * P3);
-  };
-  // one quarter of the wave tile (A pair pa x B pair pb): six products, product-outer / accumulator-inner -- dependent MFMAs are 4 apart
-  auto mfma_quarter = [&](const bf16x8_t (&fa)[3][2], const bf16x8_t (&fb)[3][2], int pa, int pb) {
-    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
-#pragma unroll
-    for (int q = 0; q < 6; ++q)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[pa * 2 + i][pb * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]][i], fb[PB[q]][j], acc[pa * 2 + i][pb * 2 + j], 0, 0, 0);
-  };
-
-  // Rolling fragment registers: four sets of 24 (A pair 0, A pair 1, B pair 0, B pair 1).  A set is reloaded for the NEXT step as soon
-  // as its last quarter of this step is done, always >= 24 MFMAs before its next use:
-  //   quarter 00 (A0 x B0): read A1, B1 of this step;  split + store tile t+1 into the other LDS buffer
-  //   quarter 01 (A0 x B1): ... store continues                                                        -> A0 free
-  //   barrier  (tile t+1 visible; nobody reads this buffer's tile t any more after quarter 00)
-  //   quarter 10 (A1 x B0): global loads of tile t+2;  read A0 of tile t+1                              -> B0 free
-  //   quarter 11 (A1 x B1): read B0 of tile t+1
-  bf16x8_t fa0[3][2], fa1[3][2], fb0[3][2], fb1[3][2];
-  load(0);
-  store(0, 0);
-  __syncthreads();
-  read_a(0, 0, fa0);
-  read_b(0, 0, fb0);
-  load(1);
-  for (int t = 0; t < nk; ++t) {
-    const int cur = t & 1;
-    read_a(cur, 1, fa1);
-    read_b(cur, 1, fb1);
-    store(cur ^ 1, t + 1);
-    load(t + 2);
-    mfma_quarter(fa0, fb0, 0, 0);
-    mfma_quarter(fa0, fb1, 0, 1);
-    // issue order of the first half: fragment reads, then the split arithmetic (~6 VALU per MFMA) with its LDS stores, then the loads
-#pragma unroll
-    for (int i = 0; i < 48; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (i < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      if (i < 22) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-      if (i >= 4 && i < 22) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-      if (i >= 22 && i < 32) { __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    read_a(cur ^ 1, 0, fa0);
-    mfma_quarter(fa1, fb0, 1, 0);
-#pragma unroll
-    for (int i = 0; i < 24; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    read_b(cur ^ 1, 0, fb0);
-    mfma_quarter(fa1, fb1, 1, 1);
-#pragma unroll
-    for (int i = 0; i < 24; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (i >= 4 && i < 10) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  __syncthreads();   // the epilogue reuses the operand buffers
-
-  // Epilogue, one 32-row band of the wave's 128 x 128 tile at a time through the 64 x 64 version's code with TM = 1: a band's rows are
-  // m0 + (wm * 4 + a) * 32 + ..., which that code computes as m0' + wm * 32 + ... with m0' = m0 + wm * 96 + a * 32.
-  float* stage = reinterpret_cast<float*>(smem_raw) + wave * (32 * (4 * 32 + 4));
-  const bool interior = m0 + C_::BM <= g.M && n0 + C_::BN <= (g.mode == SR_EPI_FWD ? g.N : (g.nact_bwd < g.N ? g.nact_bwd : g.N));
-  auto band_epilogue = [&](f32x16 (&band)[1][4], int a) __attribute__((always_inline)) {
-    const int mb = m0 + wm * 96 + a * 32;
-    if (interior) {
-      if (g.mode == SR_EPI_FWD) {
-        switch (g.group) {
-          case 1: epilogue_interior_act<2, 2, 1, 4, 1, SR_EPI_FWD>(g, band, mb, n0, wm, wn, li, kh, stage); break;
-          case 2: epilogue_interior_act<2, 2, 1, 4, 2, SR_EPI_FWD>(g, band, mb, n0, wm, wn, li, kh, stage); break;
-          default: epilogue_interior_act<2, 2, 1, 4, 4, SR_EPI_FWD>(g, band, mb, n0, wm, wn, li, kh, stage); break;
-        }
-      } else {
-        switch (g.group) {
-          case 1: epilogue_interior_act<2, 2, 1, 4, 1, SR_EPI_BWD>(g, band, mb, n0, wm, wn, li, kh, stage); break;
-          case 2: epilogue_interior_act<2, 2, 1, 4, 2, SR_EPI_BWD>(g, band, mb, n0, wm, wn, li, kh, stage); break;
-          default: epilogue_interior_act<2, 2, 1, 4, 4, SR_EPI_BWD>(g, band, mb, n0, wm, wn, li, kh, stage); break;
-        }
-      }
-    } else {
-      switch (g.group) {
-        case 1: epilogue<2, 2, 1, 4, 1>(g, band, mb, n0, wm, wn, li, kh, stage); break;
-        case 2: epilogue<2, 2, 1, 4, 2>(g, band, mb, n0, wm, wn, li, kh, stage); break;
-        default: epilogue<2, 2, 1, 4, 4>(g, band, mb, n0, wm, wn, li, kh, stage); break;
-      }
-    }
-    __syncthreads();      // the next band reuses the staging image
-  };
-  // (four literal copies: the band index must be a constant or the accumulators go through scratch memory)
-#define SR_BAND(A_)                                                                     \
-  do {                                                                                  \
-    f32x16 band[1][4] = {{acc[A_][0], acc[A_][1], acc[A_][2], acc[A_][3]}};             \
-    band_epilogue(band, A_);                                                            \
-  } while (0)
-  SR_BAND(0); SR_BAND(1); SR_BAND(2); SR_BAND(3);
-#undef SR_BAND
-}
-
-template <bool KTAIL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_bf16x3_w128_kernel(sr_gemm_args g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem3w[];
-  gemm_nt_tile_bf16x3_w128<KTAIL>(g, blockIdx.x, smem3w);
-}
-
-// x -> three bf16 planes (weights, once per optimizer step); columns [cols, ld_dst) are written as zero
-__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ src, int64_t ld_src, int64_t rows, int cols,
-                                                            unsigned short* __restrict__ dst, int64_t ld_dst, int64_t plane) {
-  const int64_t total = rows * ld_dst;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / ld_dst;
-    const int c = (int)(i - r * ld_dst);
-    unsigned int h = 0, m = 0, l = 0;
-    if (c < cols) split_bf16x3(src[r * ld_src + c], h, m, l);
-    dst[i] = (unsigned short)h; dst[plane + i] = (unsigned short)m; dst[2 * plane + i] = (unsigned short)l;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Persistent layer chain: ONE launch runs up to SR_CHAIN_MAX_LAYERS consecutive layers of one or two independent MLPs
 // (e.g. layer l of the SDF and of the deformation network side by side) on a row count that lives in DEVICE memory.
 // The workgroups of a resident grid (2 per CU) walk the tiles of a layer with a stride of the grid size and meet at a
@@ -1294,52 +807,6 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
       hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, false>), dim3(nwg), dim3(C_::kThreads), C_::kLdsFloats * sizeof(float), \
                          (hipStream_t)stream, g);                                                                           \
   } while (0)
-  // opt-in split-bf16 path: B pre-split (B3), wide output, enough rows to fill the machine with 128 x 128 tiles
-  static const int bf16x3_min_rows = getenv("SR_BF16X3_MIN_ROWS") ? atoi(getenv("SR_BF16X3_MIN_ROWS")) : 8192;
-  if (g.B3 && ncols > 32 && g.M >= bf16x3_min_rows) {
-    if ((g.ldb3 & 15) || ((uintptr_t)g.B3 & 15) || (g.plane3 & 7) || g.ldb3 < ((g.K + 15) & ~15)) return SR_EINVAL;
-    // Two tilings.  The default is 256 x 256 workgroup tiles (128 x 128 per wave, 512 registers per wave, one workgroup per CU): alone on
-    // the machine it is the faster form (164-185 against 150-156 TFLOP/s-equivalent on 262144 x 512 x 512); inside the iteration it costs
-    // ~1 ms against the 128 x 128 tiling (one workgroup per CU with 147 KB of LDS leaves no room for the weight-gradient stream's
-    // workgroups, and 87k-row launches are 2.7 rounds of 256 tiles).  It is the default because it OWNS the CUs it runs on: the
-    // 128 x 128 tiling (SR_BF16X3_TILE=128; 244 registers, two workgroups per CU) shares CUs with other streams' kernels, and kernels
-    // that share a CU with it are disturbed -- a victim micro-kernel reads garbage back from its own stack (1.7e-3 of its evaluations,
-    // tools/valu_repro.py), the hard rasteriser loses or flips 1-3 of 291,600 pixels in ~10 % of the calls (tools/raster_repeat.py) --
-    // while the GEMM's own results stay bit-reproducible and nothing is written outside its output (tools/gemm_guard.py).  It is not
-    // this kernel's doing: a 40-line synthetic wave that mixes in-flight global loads with v_mfma_f32_32x32x16_bf16 does the same to the
-    // multi-dword memory accesses of its neighbours (tools/valu_repro.hip::agg_loads, profiles/r04_bf16x3_hunt.md); the fp32 MFMA does
-    // not.  So while it issues that instruction the kernel should not share CUs -- which this tiling, like hipBLASLt's, guarantees.
-    static const int tile_sel = getenv("SR_BF16X3_TILE") ? atoi(getenv("SR_BF16X3_TILE")) : 256;
-    const int64_t big_tiles = sr_cdiv(g.M, Cfg3W::BM) * sr_cdiv(ncols, Cfg3W::BN);
-    if (tile_sel != 128) {
-      static bool attr_w = false;
-      if (!attr_w) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_bf16x3_w128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg3W::kLdsBytes) != hipSuccess ||
-            hipFuncSetAttribute((const void*)gemm_nt_bf16x3_w128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg3W::kLdsBytes) != hipSuccess)
-          return SR_ELAUNCH;
-        attr_w = true;
-      }
-      if (g.K % BK3)
-        hipLaunchKernelGGL((gemm_nt_bf16x3_w128_kernel<true>), dim3((unsigned)big_tiles), dim3(256), Cfg3W::kLdsBytes, (hipStream_t)stream, g);
-      else
-        hipLaunchKernelGGL((gemm_nt_bf16x3_w128_kernel<false>), dim3((unsigned)big_tiles), dim3(256), Cfg3W::kLdsBytes, (hipStream_t)stream, g);
-      return sr_launch_status();
-    }
-    using C3 = Cfg3<2, 2, 2, 2>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel<2, 2, 2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C3::kLdsBytes) != hipSuccess ||
-          hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel<2, 2, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C3::kLdsBytes) != hipSuccess)
-        return SR_ELAUNCH;
-      attr_set = true;
-    }
-    const int nwg = (int)(sr_cdiv(g.M, C3::BM) * sr_cdiv(ncols, C3::BN));
-    if (g.K % BK3)
-      hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<2, 2, 2, 2, true>), dim3(nwg), dim3(C3::kThreads), C3::kLdsBytes, (hipStream_t)stream, g);
-    else
-      hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<2, 2, 2, 2, false>), dim3(nwg), dim3(C3::kThreads), C3::kLdsBytes, (hipStream_t)stream, g);
-    return sr_launch_status();
-  }
   if (ncols <= 32) {
     // narrow outputs (the 3-wide deformer / render heads, the sdf-only last layer): 256x32 tiles for the template-sized batches,
     // 64x32 / 32x32 for the refiner's few thousand rows (6k rows are only 24 tiles of 256 rows on 256 CUs)
@@ -1436,15 +903,6 @@ int sr_mlp_chain(const sr_chain_args* a, void* stream) {
   if (grid <= 0) return SR_ELAUNCH;
   if (hipMemsetAsync(a->barrier, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return SR_ELAUNCH;
   hipLaunchKernelGGL(mlp_chain_kernel, dim3(grid), dim3(ChainCfg::kThreads), ChainCfg::kLdsFloats * sizeof(float), (hipStream_t)stream, *a);
-  return sr_launch_status();
-}
-
-int sr_split_bf16x3(const float* src, int64_t ld_src, int64_t rows, int32_t cols, uint16_t* dst, int64_t ld_dst, int64_t plane_stride, void* stream) {
-  if (rows < 0 || cols <= 0 || ld_src < cols || ld_dst < cols || (ld_dst & 15) || plane_stride < rows * ld_dst) return SR_EINVAL;
-  if (rows == 0) return SR_OK;
-  if (!src || !dst) return SR_EINVAL;
-  hipLaunchKernelGGL(split_bf16x3_kernel, dim3(sr_stream_grid(rows * ld_dst, 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src, rows, cols, dst, ld_dst,
-                     plane_stride);
   return sr_launch_status();
 }
 

@@ -148,48 +148,6 @@ class _GemmProfile:
 
 PROFILE = _GemmProfile()
 
-# Opt-in arithmetic of the large forward / backward-data layer GEMMs (SR_GEMM=bf16x3, or set_gemm_mode): "f32" = exact fp32 MFMA (the
-# default and the headline), "bf16x3" = every operand split into three bf16 terms, six products accumulated in fp32 on the bf16 MFMA
-# pipe (csrc/mlp_gemm.hip::gemm_nt_tile_bf16x3) -- fp32-equivalent accuracy (tests/test_mlp_gpu.py) at 6/16 of the MFMA time.  The
-# refiner's chains, the weight-gradient GEMMs and every launch below SR_BF16X3_MIN_ROWS rows stay on the fp32 path in both modes.
-GEMM_MODE = os.environ.get("SR_GEMM", "f32")
-_PLANES_BY_PTR = {}        # data_ptr of a packed weight matrix (W or WT) -> (planes int16 [3, rows, ld3], ld3)
-
-
-def set_gemm_mode(mode):
-    global GEMM_MODE
-    if mode not in ("f32", "bf16x3"):
-        raise ValueError(mode)
-    if mode != GEMM_MODE:
-        GEMM_MODE = mode
-        for e in _PACK_CACHE.values():
-            _refresh_planes(e)
-
-
-def split_bf16x3(M, K):
-    """M [rows, >= K] fp32 (unit column stride) -> int16 tensor [3, rows, round16(K)] of bf16 bit patterns: hi, mid, lo planes."""
-    rows = M.shape[0]
-    ld3 = (K + 15) // 16 * 16
-    out = torch.empty((3, rows, ld3), dtype=torch.int16, device=M.device)
-    with _lib.on_device(M.device):
-        _lib.call("sr_split_bf16x3", _lib.ptr(M), M.stride(0), rows, K, _lib.ptr(out), ld3, rows * ld3, _lib.stream_of(M))
-    return out, ld3
-
-
-def _refresh_planes(e):
-    """(Re)build the bf16 planes of a pack entry's W and WT -- called whenever the entry is (re)filled; no-op in f32 mode."""
-    for key in ("W", "WT"):
-        _PLANES_BY_PTR.pop(e[key].data_ptr(), None)
-    if GEMM_MODE != "bf16x3" or not e["W"].is_cuda:
-        e.pop("W3", None); e.pop("WT3", None)
-        return
-    N, K = e["W"].shape[0], e["WT"].shape[0]
-    e["W3"] = split_bf16x3(e["W"], K)
-    e["WT3"] = split_bf16x3(e["WT"], N)
-    _PLANES_BY_PTR[e["W"].data_ptr()] = e["W3"]
-    _PLANES_BY_PTR[e["WT"].data_ptr()] = e["WT3"]
-
-
 def _gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, group, act, mode, out_scale=1.0, aux=None, ldaux=0, naux_fwd=0,
              nact_bwd=0, aux_scale=1.0):
     a = _lib.SrGemmArgs()
@@ -198,10 +156,6 @@ def _gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, group, act, mode, out_scale=
     a.bias = _lib.ptr(bias)
     a.group, a.act, a.mode, a.out_scale = group, act, mode, out_scale
     a.aux, a.ldaux, a.naux_fwd, a.nact_bwd, a.aux_scale = _lib.ptr(aux), ldaux, naux_fwd, nact_bwd, aux_scale
-    if GEMM_MODE == "bf16x3":
-        pl = _PLANES_BY_PTR.get(B.data_ptr())
-        if pl is not None and pl[0].shape[1] >= N and ldb == B.stride(0):
-            a.B3, a.ldb3, a.plane3 = _lib.ptr(pl[0]), pl[1], pl[0].shape[1] * pl[1]
     if PROFILE.enabled and M >= 128 and N > 32:      # the 128x128-tile kernel only
         e0, e1 = PROFILE.pair()
         e0.record()
@@ -567,7 +521,6 @@ def _sig(*ts):
 def _drop_entry(key):
     e = _PACK_CACHE.pop(key, None)
     if e is not None:
-        _PLANES_BY_PTR.pop(e["W"].data_ptr(), None); _PLANES_BY_PTR.pop(e["WT"].data_ptr(), None)
         _WT_BY_PTR.pop(e["W"].data_ptr(), None)
         _ENTRY_BY_PTR.pop(e["W"].data_ptr(), None)
 
@@ -579,7 +532,6 @@ def _pack_entry(key, sig, build, owner=None):
     if e is None or e["sig"] != sig:
         if e is not None:
             _WT_BY_PTR.pop(e["W"].data_ptr(), None)
-            _PLANES_BY_PTR.pop(e["W"].data_ptr(), None); _PLANES_BY_PTR.pop(e["WT"].data_ptr(), None)
         if e is not None and e.get("dirty"):
             raise RuntimeError("mlp_engine: parameters changed while deferred gradients were pending; call flush_param_grads() "
                                "before the optimizer step")
@@ -590,7 +542,6 @@ def _pack_entry(key, sig, build, owner=None):
         _PACK_CACHE[key] = e
         _WT_BY_PTR[e["W"].data_ptr()] = e["WT"]
         _ENTRY_BY_PTR[e["W"].data_ptr()] = e
-        _refresh_planes(e)
     return e
 
 
@@ -687,7 +638,6 @@ def refresh_packs(lins):
             _lib.call("sr_pack_weights", ctypes.byref(t), _lib.stream_of(chunk[0][1]))
         for e, v, g, sig in chunk:
             e["sig"] = sig
-            _refresh_planes(e)
         # The kernel wrote W / WT / norms behind torch's version counters.  Bump them (host-only, no launch): a graph that saved the
         # OLD values -- a retained graph, gradient accumulation over two forwards with an optimizer step in between, a delayed
         # backward -- now raises autograd's "modified by an inplace operation" error instead of silently back-propagating with

@@ -16,7 +16,6 @@ Deliberate differences (all documented in DESIGN.md):
 """
 import contextlib
 import os
-
 import time
 import numpy as np
 import torch
@@ -36,10 +35,14 @@ from .CameraMine import RectifiedPerspectiveCameras
 
 
 SPLIT_SAMPLE_TERMS = os.environ.get('SR_SPLIT_SAMPLE_TERMS', '0') != '0'    # see forward(): refiner-independent part of the sampled terms first
-# The eikonal term and the deformation regulariser each on a stream of their own (autograd runs a node's backward on the stream of its
-# forward, so their reverse sweeps -- three independent chains of large layer launches with the |f(TmpVs)| sweep -- overlap as well and
-# fill each other's last partial round of tiles).  Tuning switch, see DESIGN.md section 4.
-BRANCH_STREAMS = os.environ.get('SR_BRANCH_STREAMS', '0') != '0'
+# The ray branch -- everything that hangs on the CONVERGED rays: colour + normal terms, their backward, the implicit-gradient pass
+# (network.py:599-639, 702-814) -- is a chain of a few hundred SMALL launches (1-5k rows) paced by the host, and nothing on the
+# main stream needs its results before the optimizer step.  With the switch on it runs on the high-priority side stream NEXT TO the
+# large launches of the sampled terms and their backward: forward() back-propagates the colour / normal terms at once (an inner
+# backward, like the template step's) into detached stand-ins of the per-frame / camera tensors, propagateTmpPsGrad runs on the same
+# stream, and the stand-ins' gradients are handed to the real leaves when the two streams join (OptimNetwork._finish_ray_branch).
+# Every parameter gradient is the same sum of the same terms; off = one backward of the total loss, as the reference writes it.
+EAGER_RAY_BRANCH = os.environ.get('SR_EAGER_RAY_BRANCH', '1') != '0'
 _SIDE_STREAMS = {}
 
 
@@ -359,6 +362,7 @@ class OptimNetwork(nn.Module):
         if self.angThred is None:
             self.angThred = cameras.angThreshold(0.5)
         self.info = {}
+        self._finish_ray_branch()                    # (a branch of the previous call that no propagateTmpPsGrad closed)
         if self.TmpVs is None or self.Tmpfs is None or self.forward_time % self.remesh_intersect == 0:
             ev = getattr(self, 'remesh_events', None)
             if ev is not None:                       # bench.py: duration of the remesh inside the timed window
@@ -530,16 +534,6 @@ class OptimNetwork(nn.Module):
             debug.update(initTmpPs=initTmpPs, check=check, rays=rays)
 
         # --- eikonal (network.py:543-549; sample_points utils.py:74-84)
-        bstreams = None
-        if BRANCH_STREAMS and not split and not mlp_engine.PROFILE.enabled:
-            bstreams = (self._side_stream(device, 2), self._side_stream(device, 3))
-            joined = torch.cuda.Event()
-            joined.record(main)
-            for st in bstreams:
-                st.wait_event(joined)
-                for t in (initTmpPs, nl, ng):
-                    t.record_stream(st)
-        eik_ctx = torch.cuda.stream(bstreams[0]) if bstreams else contextlib.nullcontext()
         if split:
             eikB_pts = initTmpPs + nl[:nr] * 0.01
             eikB = self._eikonal_mean(eikB_pts, ratio)
@@ -547,31 +541,27 @@ class OptimNetwork(nn.Module):
             grad_loss = eikA * (float(nA) / float(nA + nB)) + eikB * (float(nB) / float(nA + nB))
             self._eik_pts = torch.cat([eikB_pts.detach(), eikA_pts.detach()], dim=0)      # the reference's order: rays, vertices, uniform
         else:
-            with eik_ctx:
-                base = torch.cat([initTmpPs, self.TmpVs.detach()[eik_idx]], dim=0)
-                pts = torch.cat([base + nl * 0.01, ng * (1.8 * 2) - 1.8], dim=0)
-                self._eik_pts = pts.detach()
-                grad_loss = self._eikonal_mean(pts, ratio)
+            base = torch.cat([initTmpPs, self.TmpVs.detach()[eik_idx]], dim=0)
+            pts = torch.cat([base + nl * 0.01, ng * (1.8 * 2) - 1.8], dim=0)
+            self._eik_pts = pts.detach()
+            grad_loss = self._eikonal_mean(pts, ratio)
         self._mark('eikonal issued')
-        if not bstreams:
-            self.info['grad_loss'] = grad_loss.detach()
-            wpool = srdist.pooled_mean_weight(n_base, device)      # N > 1 ranks: pooled mean over the points of all ranks (caveat B)
-            if wpool is not None:
-                grad_loss = grad_loss * wpool
-            total_loss = total_loss + grad_loss * self.conf.get_float('grad_weight')
+        self.info['grad_loss'] = grad_loss.detach()
+        wpool = srdist.pooled_mean_weight(n_base, device)      # N > 1 ranks: pooled mean over the points of all ranks (caveat B)
+        if wpool is not None:
+            grad_loss = grad_loss * wpool
+        total_loss = total_loss + grad_loss * self.conf.get_float('grad_weight')
 
         # --- offset regulariser (network.py:552-560): mean |deformation-MLP offset| on the eikonal sample points; logged without
         # gradient when its weight is 0 (both shipped configs), part of the loss when it is positive
         ow = self.conf.get_float('offset_weight') if 'offset_weight' in self.conf else -1.
-        if bstreams and ow > 0.:
-            main.wait_stream(bstreams[0])        # the term joins the loss on the main stream: the sample points must be there
         if ow > 0.:
             self.deformer.defs[0](self._eik_pts.view(1, -1, 3).expand(N, -1, 3), d_cond, ratio=ratio)
             offset_loss = self.deformer.defs[0].offset.view(-1, 3).norm(p=2, dim=-1).mean()
             total_loss = total_loss + offset_loss * ow
             self.info['offset_loss'] = offset_loss.detach()
         elif ow == 0.:
-            with torch.no_grad(), (torch.cuda.stream(bstreams[0]) if bstreams else contextlib.nullcontext()):      # (logged only: stays with the eikonal samples' stream)
+            with torch.no_grad():
                 self.deformer.defs[0](self._eik_pts.view(1, -1, 3).expand(N, -1, 3), d_cond.detach(), ratio=ratio)
                 self.info['offset_loss'] = self.deformer.defs[0].offset.view(-1, 3).norm(p=2, dim=-1).mean()
 
@@ -582,26 +572,13 @@ class OptimNetwork(nn.Module):
                 nA, nB = regu_idx.shape[0], nr
                 def_loss = defA * (float(nA) / float(nA + nB)) + defB * (float(nB) / float(nA + nB))
             else:
-                with (torch.cuda.stream(bstreams[1]) if bstreams else contextlib.nullcontext()):
-                    if bstreams:
-                        nl2.record_stream(bstreams[1])
-                    pts = torch.cat([initTmpPs, self.TmpVs.detach()[regu_idx]], dim=0)
-                    def_loss = self._def_regu_mean(torch.cat([pts, pts + nl2 * 0.01], dim=0), d_cond, N, ratio)
-            if bstreams:
-                main.wait_stream(bstreams[1])
+                pts = torch.cat([initTmpPs, self.TmpVs.detach()[regu_idx]], dim=0)
+                def_loss = self._def_regu_mean(torch.cat([pts, pts + nl2 * 0.01], dim=0), d_cond, N, ratio)
             self.info['def_loss'] = def_loss.detach()
             wpool = srdist.pooled_mean_weight(n_regu, device)
             if wpool is not None:
                 def_loss = def_loss * wpool
             total_loss = total_loss + def_loss * self.conf.get_float('def_regu.weight')
-
-        if bstreams:                       # the eikonal term joins here (its stream ran under the regulariser's forward)
-            main.wait_stream(bstreams[0])
-            self.info['grad_loss'] = grad_loss.detach()
-            wpool = srdist.pooled_mean_weight(n_base, device)
-            if wpool is not None:
-                grad_loss = grad_loss * wpool
-            total_loss = total_loss + grad_loss * self.conf.get_float('grad_weight')
         self._mark('def-regu issued')
         # --- DCT temporal smoothness (network.py:585-593)
         if (poses.requires_grad or trans.requires_grad) and self.conf.get_float('dct_weight') > 0. and self.dctnull is not None:
@@ -617,16 +594,55 @@ class OptimNetwork(nn.Module):
         with torch.cuda.stream(side):
             side.wait_event(refined)
             conv_idx = hostsync.nonzero(check).view(-1)
-        main.wait_stream(side)
         self._mark('converged rays known')
-        conv_idx.record_stream(main)
         nconv = conv_idx.numel()
+        # The ray branch (see EAGER_RAY_BRANCH): on the side stream -- which is idle from here on -- when the weight-gradient launches
+        # have their own ordered stream (deferred mode); otherwise on the main stream, same program order.
+        eager = EAGER_RAY_BRANCH and torch.is_grad_enabled() and nconv > 0
+        on_rb_side = (eager and on_side and mlp_engine.DEFERRED_PARAM_GRADS and mlp_engine.TN_SIDE_STREAM and not mlp_engine.PROFILE.enabled)
+        rb = side if on_rb_side else main
+        if not on_rb_side:
+            main.wait_stream(side)
+            conv_idx.record_stream(main)
         if nconv > 0:
-            self.TmpPs = initTmpPs[conv_idx]
-            self.TmpPs.requires_grad = True
-            self.rays = rays[conv_idx]
-            self.batch_inds, self.col_inds, self.row_inds = batch_inds[conv_idx], col_inds[conv_idx], row_inds[conv_idx]
-            extra = self.loss_color_normal(datas, gtCs, cameras, defconds, rendcond, ratio, N)
+            ctx = None
+            if eager:
+                # the real per-frame / camera tensors (graph to the dataset's leaves, made on the MAIN stream): only the hand-over of
+                # the stand-ins' gradients goes through them, after the streams have joined
+                dep = [t for t in self.dataset.get_grad_parameters(frame_ids, device)] + (list(self.dataset.get_camera_parameters(N, device)[:4]) if cam_learn else [])
+            with torch.cuda.stream(rb):
+                if eager:
+                    with torch.no_grad():
+                        vals = list(self.dataset.get_grad_parameters(frame_ids, device)) + (list(self.dataset.get_camera_parameters(N, device)[:4]) if cam_learn else [])
+                    prox = [v.detach().requires_grad_(o.requires_grad) for v, o in zip(vals, dep)]
+                    r_poses, r_trans, r_dcond, r_rendcond = prox[:4]
+                    r_cameras = RectifiedPerspectiveCameras(*prox[4:8], image_size=[(W, H)]) if cam_learn else cameras
+                    ctx = {'stream': rb, 'pairs': [(o, p_) for o, p_ in zip(dep, prox) if o.requires_grad], 'cameras': r_cameras,
+                           'frame': (r_poses, r_trans, r_dcond), 'main': main}
+                    for t in (gtCs, datas['normal']) if 'normal' in datas else (gtCs,):
+                        if on_rb_side and torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(rb)
+                else:
+                    r_poses, r_trans, r_dcond, r_rendcond, r_cameras = poses, trans, d_cond, rendcond, cameras
+                self.TmpPs = initTmpPs[conv_idx]
+                self.TmpPs.requires_grad = True
+                self.batch_inds, self.col_inds, self.row_inds = batch_inds[conv_idx], col_inds[conv_idx], row_inds[conv_idx]
+                # (the rays of the converged pixels from the branch's own camera object: the same rows as rays[conv_idx], bit for bit)
+                self.rays = r_cameras.view_rays(pixels[conv_idx]) if (eager and cam_learn) else rays[conv_idx]
+                extra = self.loss_color_normal(datas, gtCs, r_cameras, [r_dcond, [r_poses, r_trans]], r_rendcond, ratio, N)
+                if eager and torch.is_tensor(extra) and extra.requires_grad:
+                    value = extra.detach()
+                    known = torch.cuda.Event()
+                    known.record(rb)
+                    self._mark('ray branch forward issued')
+                    extra.backward()                     # inner backward: TmpPs.grad, the stand-ins' gradients, the deferred weight gradients
+                    ctx['bwd_done'] = torch.cuda.Event()
+                    ctx['bwd_done'].record(rb)
+                    self._ray_ctx = ctx
+                    if on_rb_side:
+                        main.wait_event(known)           # (the VALUE of the two terms joins the returned loss; the forward of the branch is
+                        value.record_stream(main)        #  queued long before the main stream gets here)
+                    extra = value
             total_loss = total_loss + extra
 
         self.remesh_time = np.floor(self.remesh_time) + float(self.forward_time % self.remesh_intersect) / float(self.remesh_intersect)
@@ -634,6 +650,30 @@ class OptimNetwork(nn.Module):
         self.forward_time += 1
         self._mark('forward issued')
         return total_loss
+
+    def _finish_ray_branch(self, final=True):
+        """Hands the gradients the ray branch's stand-ins have collected (colour / normal backward, implicit-gradient pass) to the
+        dataset's real per-frame / camera leaves -- one tiny backward on the main stream through the gathers that produced them.
+        `final`: the branch is over (the main stream joins its stream); otherwise only what the inner backward of forward() left is
+        handed over (the distributed step wants the render codes' gradient before its early all-reduce)."""
+        ctx = getattr(self, '_ray_ctx', None)
+        if ctx is None:
+            return
+        main, rb = ctx['main'], ctx['stream']
+        if final:
+            self._ray_ctx = None
+        if rb is not main:
+            main.wait_stream(rb) if final else main.wait_event(ctx['bwd_done'])
+        outs, grads = [], []
+        for o, p_ in ctx['pairs']:
+            if p_.grad is not None:
+                outs.append(o); grads.append(p_.grad)
+                if rb is not main:
+                    p_.grad.record_stream(main)
+                p_.grad = None
+        if outs:
+            with torch.cuda.stream(main):
+                torch.autograd.backward(outs, grads, retain_graph=not final)
 
     # ------------------------------------------------------------------ loss terms (a14)
     def _eikonal_mean(self, pts, ratio):
@@ -784,66 +824,75 @@ class OptimNetwork(nn.Module):
         `overlap` (extension): a dist.GradBucket whose early group (gradients this pass does not touch) is all-reduced
         asynchronously while the pass runs."""
         if overlap is not None and srdist.is_distributed():
+            self._finish_ray_branch(final=False)                      # (the render codes' gradient, if the colour term reaches them)
             mlp_engine.flush_param_grads(only=overlap.early_ids)      # their deferred weight gradients are final: materialise them now
             overlap.start_early()
+        ctx = getattr(self, '_ray_ctx', None)
         if self.TmpPs is None or self.TmpPs.grad is None:
             self.info['invInfo'] = (-1, -1)
+            self._finish_ray_branch()
             mlp_engine.flush_param_grads()
             return
         device = self.TmpPs.device
-        poses, trans, d_cond, _ = self.dataset.get_grad_parameters(frame_ids, device)
-        defconds = [d_cond, [poses, trans]]
-        grad_l_p = self.TmpPs.grad
-        # rays / camera centre: rebuilt from the (possibly learnable) camera parameters, network.py:715-719
-        cameras, H, W = self._cameras(frame_ids.numel(), device)
-        if self.rays.requires_grad:
-            pixels = torch.stack([self.col_inds, self.row_inds, torch.ones_like(self.col_inds)], dim=-1).float()
-            v_live = cameras.view_rays(pixels)
-        else:
-            v_live = self.rays
-        c_live = cameras.cam_pos()
-        v = v_live.detach()
-        p = self.TmpPs
-        f = self.sdf(p, ratio, sdf_only=True)
-        with mlp_engine.input_grads_only():
-            grad_f_p = torch.autograd.grad(f, p, torch.ones_like(f), retain_graph=True)[0]
-        d, grad_d_p = U.deformed_points_and_jacobian(self.deformer, p, defconds, self.batch_inds, ratio, True)
-        grad_d_p = grad_d_p.detach()                                   # graphs of f and d are kept: they are back-propagated below
-        opt_defconds = [t for t in (d_cond, poses, trans) if t.requires_grad]
-        # The reference builds a surrogate loss sum(param * grad) from three autograd.grad calls and back-propagates it
-        # (network.py:773-814); that adds `grad` to every parameter's .grad, which is exactly one backward of
-        # (f, d) with the cotangents (-rhs_f, temp).
-        # (The reference evaluates f and d a second time at p.detach() for this; the weights have not moved since the evaluations
-        # above, so those graphs are reused and the backward is restricted to the learnable leaves -- p itself gets no gradient.)
-        f2, d2 = f, d
-        if step_ops.ENABLED and p.is_cuda:
-            # b = [grad f ; [v]x J], (b^T b)^-1 (FastMinv's rule), rhs = grad_l^T (b^T b)^-1 b^T, rhs[1:4] (-[v]x): one kernel
-            cot_f, rhs_tail, temp, check = step_ops.implicit_solve(grad_f_p, grad_d_p, v, grad_l_p)
-            self.info['invInfo'] = (check.numel(), check.sum())
-            cot_f, rhs_tail = cot_f.view(f2.shape), rhs_tail.view(-1, 1, 3)
-        else:
-            v_cross = cross_matrix(v)
-            b = torch.cat([grad_f_p.view(-1, 1, 3), U.small_matmul(v_cross, grad_d_p)], dim=1)
-            btb = U.small_matmul(b.permute(0, 2, 1), b)
-            btb_inv, check = Fast3x3Minv(btb.contiguous())
-            self.info['invInfo'] = (check.numel(), check.sum())
-            rhs_1 = U.small_matmul(grad_l_p.view(-1, 1, 3), U.small_matmul(btb_inv, b.permute(0, 2, 1)))        # [P,1,4]
-            rhs_tail = rhs_1[:, :, -3:]
-            temp = U.small_matmul(rhs_tail, -v_cross).view(-1, 3).detach()
-            cot_f = (-rhs_1[:, :, 0]).reshape(f2.shape).detach()
-        outs, cots = [f2, d2], [cot_f, temp]
-        if v_live.requires_grad:                      # d/dv of [v]x (d - c): network.py:798-809
-            dc_cross = cross_matrix(d2.detach() - c_live.detach().view(1, 3))
-            outs.append(v_live); cots.append(U.small_matmul(rhs_tail, dc_cross).view(-1, 3).detach())
-        if c_live.requires_grad:                      # network.py:811-813
-            outs.append(c_live); cots.append((-temp.sum(0)).detach())
-        lw = getattr(self.dataset, 'learnable_weights', None)
-        if lw is None:
-            torch.autograd.backward(outs, cots)               # (TmpPs.grad also receives a contribution nobody reads)
-        else:
-            leaves, seen = [], set()
-            for t in list(self.sdf.parameters()) + list(self.deformer.parameters()) + list(lw()):
-                if t.requires_grad and t.is_leaf and id(t) not in seen:
-                    seen.add(id(t)); leaves.append(t)
-            torch.autograd.backward(outs, cots, inputs=leaves)
+        # With a pending ray branch (forward() back-propagated the colour / normal terms on its stream, EAGER_RAY_BRANCH) the pass runs
+        # on that stream with the branch's stand-ins of the per-frame / camera tensors; called on its own it uses the real ones.
+        with torch.cuda.stream(ctx['stream']) if ctx is not None else contextlib.nullcontext():
+            if ctx is not None:
+                (poses, trans, d_cond), cameras = ctx['frame'], ctx['cameras']
+            else:
+                poses, trans, d_cond, _ = self.dataset.get_grad_parameters(frame_ids, device)
+                cameras, H, W = self._cameras(frame_ids.numel(), device)        # rays / camera centre: rebuilt from the (possibly learnable) camera parameters, network.py:715-719
+            defconds = [d_cond, [poses, trans]]
+            grad_l_p = self.TmpPs.grad
+            if self.rays.requires_grad:
+                pixels = torch.stack([self.col_inds, self.row_inds, torch.ones_like(self.col_inds)], dim=-1).float()
+                v_live = cameras.view_rays(pixels)
+            else:
+                v_live = self.rays
+            c_live = cameras.cam_pos()
+            v = v_live.detach()
+            p = self.TmpPs
+            f = self.sdf(p, ratio, sdf_only=True)
+            with mlp_engine.input_grads_only():
+                grad_f_p = torch.autograd.grad(f, p, torch.ones_like(f), retain_graph=True)[0]
+            d, grad_d_p = U.deformed_points_and_jacobian(self.deformer, p, defconds, self.batch_inds, ratio, True)
+            grad_d_p = grad_d_p.detach()                                   # graphs of f and d are kept: they are back-propagated below
+            # The reference builds a surrogate loss sum(param * grad) from three autograd.grad calls and back-propagates it
+            # (network.py:773-814); that adds `grad` to every parameter's .grad, which is exactly one backward of
+            # (f, d) with the cotangents (-rhs_f, temp).
+            # (The reference evaluates f and d a second time at p.detach() for this; the weights have not moved since the evaluations
+            # above, so those graphs are reused and the backward is restricted to the learnable leaves -- p itself gets no gradient.)
+            f2, d2 = f, d
+            if step_ops.ENABLED and p.is_cuda:
+                # b = [grad f ; [v]x J], (b^T b)^-1 (FastMinv's rule), rhs = grad_l^T (b^T b)^-1 b^T, rhs[1:4] (-[v]x): one kernel
+                cot_f, rhs_tail, temp, check = step_ops.implicit_solve(grad_f_p, grad_d_p, v, grad_l_p)
+                self.info['invInfo'] = (check.numel(), check.sum())
+                cot_f, rhs_tail = cot_f.view(f2.shape), rhs_tail.view(-1, 1, 3)
+            else:
+                v_cross = cross_matrix(v)
+                b = torch.cat([grad_f_p.view(-1, 1, 3), U.small_matmul(v_cross, grad_d_p)], dim=1)
+                btb = U.small_matmul(b.permute(0, 2, 1), b)
+                btb_inv, check = Fast3x3Minv(btb.contiguous())
+                self.info['invInfo'] = (check.numel(), check.sum())
+                rhs_1 = U.small_matmul(grad_l_p.view(-1, 1, 3), U.small_matmul(btb_inv, b.permute(0, 2, 1)))        # [P,1,4]
+                rhs_tail = rhs_1[:, :, -3:]
+                temp = U.small_matmul(rhs_tail, -v_cross).view(-1, 3).detach()
+                cot_f = (-rhs_1[:, :, 0]).reshape(f2.shape).detach()
+            outs, cots = [f2, d2], [cot_f, temp]
+            if v_live.requires_grad:                      # d/dv of [v]x (d - c): network.py:798-809
+                dc_cross = cross_matrix(d2.detach() - c_live.detach().view(1, 3))
+                outs.append(v_live); cots.append(U.small_matmul(rhs_tail, dc_cross).view(-1, 3).detach())
+            if c_live.requires_grad:                      # network.py:811-813
+                outs.append(c_live); cots.append((-temp.sum(0)).detach())
+            lw = getattr(self.dataset, 'learnable_weights', None)
+            if lw is None:
+                torch.autograd.backward(outs, cots)               # (TmpPs.grad also receives a contribution nobody reads)
+            else:
+                leaves, seen = [], set()
+                frame_leaves = list(lw()) if ctx is None else [p_ for _, p_ in ctx['pairs']]
+                for t in list(self.sdf.parameters()) + list(self.deformer.parameters()) + frame_leaves:
+                    if t.requires_grad and t.is_leaf and id(t) not in seen:
+                        seen.add(id(t)); leaves.append(t)
+                torch.autograd.backward(outs, cots, inputs=leaves)
+        self._finish_ray_branch()
         mlp_engine.flush_param_grads()       # last gradient producer of the step (no-op unless deferred mode is on)

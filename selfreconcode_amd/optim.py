@@ -3,7 +3,9 @@ whole update in ONE kernel launch (csrc/small_ops.hip::adam_step_kernel) instead
 with ~40 us of host time between them: 9 ms of GPU idle per 230 launches in the round-2 trace).  Same update rule, same state layout
 (`step`, `exp_avg`, `exp_avg_sq` per parameter: a torch.optim.Adam state_dict loads, and this one's loads into torch.optim.Adam), same
 `param_groups` (the learning-rate schedulers of torch work on it unchanged).  weight_decay / amsgrad / maximize are not implemented
-(the reference uses none of them) and raise."""
+(the reference uses none of them) and raise.  Inside the optimizer `step` is a Python float (torch keeps a host tensor and pays one
+aten `add_` per parameter and step: ~60 operator calls per iteration here); `state_dict()` writes it out as the host tensor torch's Adam
+keeps, `load_state_dict()` takes either form."""
 import ctypes
 import math
 
@@ -39,10 +41,10 @@ class FusedAdam(torch.optim.Optimizer):
                 if len(st) == 0:
                     if p.grad.is_sparse or p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
                         raise RuntimeError("FusedAdam: dense contiguous float32 GPU parameters only")
-                    st['step'] = torch.tensor(0.0)                      # host tensor, as torch.optim.Adam keeps it (capturable=False)
+                    st['step'] = 0.0
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st['step'] += 1
+                st['step'] = float(st['step']) + 1.0                    # (a loaded state may hold torch's host tensor)
                 todo.append((p, p.grad if p.grad.is_contiguous() else p.grad.contiguous(), st, group))
         if not todo:
             return loss
@@ -83,3 +85,9 @@ class FusedAdam(torch.optim.Optimizer):
                 _lib.call("sr_adam_step", ctypes.byref(t), stream)
         torch.autograd.graph.increment_version([p for p, _, _, _ in todo])      # the kernel wrote the parameters behind torch's version counters
         return loss
+
+    def state_dict(self):
+        sd = super().state_dict()
+        # (copies of the per-parameter dicts: torch hands out the optimizer's own) with `step` in the form torch.optim.Adam saves (capturable=False)
+        sd['state'] = {k: dict(st, step=torch.tensor(float(st['step']))) if 'step' in st else dict(st) for k, st in sd['state'].items()}
+        return sd

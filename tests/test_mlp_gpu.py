@@ -260,7 +260,7 @@ def test_sdf_forward_backward_at_96k_rows_vs_fp64():
     close(ours[0], ref[0].float(), 1e-4, 1e-4 * float(ref[0].abs().max()))
     for n, a, b in zip(names, ours[1:], ref[1:]):
         # sums over 98k rows: fp32 accumulation (fixed slab order) against float64
-        torch.testing.assert_close(a.cpu(), b.float(), rtol=2e-4, atol=4e-5 * max(1e-3, float(b.abs().max())), msg=lambda m, n=n: n + ": " + m)      # (sums over 98k rows in float32: 4e-5 of the largest entry; was 2e-5, met by the fp32 kernels and missed on 3 of 20k entries by the split-bf16 ones)
+        torch.testing.assert_close(a.cpu(), b.float(), rtol=2e-4, atol=4e-5 * max(1e-3, float(b.abs().max())), msg=lambda m, n=n: n + ": " + m)      # (sums over 98k rows in float32: 4e-5 of the largest entry)
 
 
 def test_fused_pack_refresh_and_fused_flush_match_torch_weight_norm():
@@ -384,74 +384,3 @@ def test_rows_frame_sum_is_exact_and_reproducible():
         assert torch.equal(a, b)
         want = torch.zeros(n, E, dtype=torch.float64, device=DEV).index_add(0, idx, X.double())
         torch.testing.assert_close(a.double(), want, rtol=1e-5, atol=4e-6 * max(1.0, P / n) ** 0.5)        # float32 partial sums of ~P/n terms of size <= 1
-
-
-def test_bf16x3_gemm_is_fp32_accurate():
-    """The opt-in split-bf16 layer GEMM (three bf16 terms per operand, six products, fp32 accumulation on the bf16 MFMA pipe) against
-    float64, next to the exact-fp32 MFMA kernel on the same operands: forward epilogues (none / Softplus / ReLU, tangent groups, the
-    skip filler), the backward-data epilogue, ragged M / N / K (K = 39, 167, 473; N = 257, 473), operands spanning 12 orders of
-    magnitude.  Its error must not exceed 1.5 x the fp32 kernel's (measured: it is smaller) and stay below 1e-6 of sum |a||b|."""
-    from selfreconcode_amd import mlp_engine as me
-    torch.manual_seed(0)
-    worst = []
-    for (M, N, K, act, group, mode, nfill) in ((16384, 512, 512, me.ACT_SOFTPLUS100, 1, me.EPI_FWD, 0), (8192, 512, 39, me.ACT_SOFTPLUS100, 4, me.EPI_FWD, 0),
-                                              (12288, 473, 512, me.ACT_SOFTPLUS100, 1, me.EPI_FWD, 39), (8200, 257, 512, me.ACT_NONE, 2, me.EPI_FWD, 0),
-                                              (9001 * 1, 512, 167, me.ACT_RELU, 1, me.EPI_FWD, 0), (16384, 512, 473, me.ACT_SOFTPLUS100, 1, me.EPI_BWD, 0),
-                                              (8192, 512, 512, me.ACT_NONE, 1, me.EPI_FWD, 0)):
-        M = M // group * group
-        A = (torch.randn(M, me.pad4(K), device=DEV) * torch.exp(torch.randn(M, 1, device=DEV) * 3.0)).contiguous()
-        if act == me.ACT_SOFTPLUS100:
-            A = A.clamp(-3, 3) * 0.3
-        B = (torch.randn(N, me.pad4(K), device=DEV) * 0.05).contiguous()
-        A[:, K:] = 0; B[:, K:] = 0
-        bias = torch.randn(N, device=DEV) * 0.01 if mode == me.EPI_FWD else None
-        aux = None
-        kw = dict(out_scale=0.7)
-        if mode == me.EPI_BWD:
-            aux = (torch.rand(M, me.pad4(N), device=DEV) * 0.05).contiguous()            # stored activations of the previous layer
-            kw = dict(out_scale=1.0, aux=aux, ldaux=aux.stride(0), nact_bwd=N, aux_scale=1.0)
-        elif nfill:
-            aux = torch.randn(M, me.pad4(nfill), device=DEV).contiguous()
-            kw = dict(out_scale=0.7, aux=aux, ldaux=aux.stride(0), naux_fwd=nfill)
-        outs = {}
-        planes = me.split_bf16x3(B, K)
-        for tag in ("f32", "bf16x3"):
-            C = torch.zeros(M, me.pad4(N + nfill), device=DEV)
-            me.GEMM_MODE = tag
-            if tag == "bf16x3":
-                me._PLANES_BY_PTR[B.data_ptr()] = planes
-            try:
-                me._gemm_nt(A, A.stride(0), B, B.stride(0), C, C.stride(0), M, N, K, bias, group, act, mode, **kw)
-            finally:
-                me.GEMM_MODE = "f32"
-                me._PLANES_BY_PTR.pop(B.data_ptr(), None)
-            outs[tag] = C
-        # float64 reference of the raw contraction, pushed through the same epilogue by comparing the two kernels' outputs on it
-        acc = A[:, :K].double() @ B[:, :K].double().t()
-        scale = A[:, :K].abs().double() @ B[:, :K].abs().double().t() + 1e-300
-        if act == me.ACT_NONE and mode == me.EPI_FWD:
-            ref = (acc + bias.double()) * kw["out_scale"] if group == 1 else None
-            if ref is not None:
-                den = scale + bias.double().abs()
-                e32 = float(((outs["f32"][:, :N].double() - ref).abs() / den).max()); e3 = float(((outs["bf16x3"][:, :N].double() - ref).abs() / den).max())
-                assert e3 < 1e-6 and e3 <= 1.5 * e32 + 1e-9, (M, N, K, e32, e3)
-                worst.append((M, N, K, e32, e3))
-        # all epilogues: the two kernels agree to fp32 GEMM accuracy on every output column (incl. tangent rows and the filler)
-        d = (outs["bf16x3"].double() - outs["f32"].double()).abs()
-        lim = 4e-6 * (scale.amax(1, keepdim=True) if True else 1.0) * (100.0 if act == me.ACT_SOFTPLUS100 and group > 1 else 1.0) + 1e-7
-        assert bool((d[:, :N] <= lim).all()), (M, N, K, act, group, mode, float((d[:, :N] / lim).max()))
-        if nfill:
-            assert torch.equal(outs["bf16x3"][:, N:N + nfill], outs["f32"][:, N:N + nfill])
-    print("errors / sum|a||b| (fp32 MFMA, bf16x3):", worst)
-
-
-def test_bf16x3_other_tiling_in_a_subprocess():
-    """The tiling of the split-bf16 GEMM is read once per process (SR_BF16X3_TILE; default 256 = 128 x 128 wave tiles with the
-    accumulators in AGPRs, edge tiles through the generic epilogue band by band): the accuracy test above ran under the default, a
-    child process re-runs it under the 128 x 128 workgroup tiling."""
-    import os, subprocess, sys
-    env = dict(os.environ, SR_BF16X3_TILE="128")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_bf16x3_gemm_is_fp32_accurate"], env=env, capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "1 passed" in r.stdout

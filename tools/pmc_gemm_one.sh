@@ -1,5 +1,5 @@
 #!/bin/bash
-# Counter passes over one GEMM kernel (each pass its own run; --kernel-trace + --pmc only).  Usage: tools/pmc_gemm_one.sh OUT f32|bf16x3
+# Counter passes over one GEMM kernel (each pass its own run; --kernel-trace + --pmc only).  Usage: tools/pmc_gemm_one.sh OUT f32
 R=$PWD; out=$R/$1; mode=$2
 mkdir -p $out; cd /tmp; export TMPDIR=/tmp
 i=0

@@ -7,7 +7,7 @@ set -u
 TAG=${1:-r04}
 R=$PWD; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_INSTS_VALU --output-format csv -d $OUT/pmc_mfma -- python $R/bench.py --steps 6 --warmup 0 --settle 0 --settle-low 0 --noise-observations --no-fine --no-cpu-baseline --no-bf16x3-record --no-extra-records --no-sdf-throughput --shape-log $OUT/pmc_shapes_mfma.json > $OUT/pmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_INSTS_VALU --output-format csv -d $OUT/pmc_mfma -- python $R/bench.py --steps 6 --warmup 0 --settle 0 --settle-low 0 --noise-observations --no-fine --no-cpu-baseline --no-extra-records --no-sdf-throughput --shape-log $OUT/pmc_shapes_mfma.json > $OUT/pmc_mfma.log 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]

@@ -7,7 +7,7 @@ R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-PROF="python $R/bench.py --steps 30 --warmup 5 --settle 0 --settle-low 10 --noise-observations --no-fine --no-cpu-baseline --no-bf16x3-record ${PROFILE_EXTRA:-}"
+PROF="python $R/bench.py --steps 30 --warmup 5 --settle 0 --settle-low 10 --noise-observations --no-fine --no-cpu-baseline ${PROFILE_EXTRA:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $PROF > $OUT/stats.log 2>&1
 python $R/tools/gap_analysis.py $OUT/stats 17 44 > $OUT/gaps.txt 2>&1
 python $R/tools/iteration_timeline.py $OUT/stats 45 > $OUT/timeline.txt 2>&1

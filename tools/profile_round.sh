@@ -14,14 +14,14 @@ python $R/bench.py --steps 20 --warmup 5 --shape-log $OUT/gemm_shapes.json > $OU
 # 2. per-kernel statistics.  The profiled command skips the render + settle phases (their kernels would swamp the table) and reaches
 #    the timed regime directly (the coarse stage at the configuration's lr 1e-4); its own JSON line (kept) reports the converged
 #    fraction it ran at.
-PROF="python $R/bench.py --steps 30 --warmup 5 --settle 0 --settle-low 0 --noise-observations --no-fine --no-cpu-baseline --no-bf16x3-record --no-extra-records"
+PROF="python $R/bench.py --steps 30 --warmup 5 --settle 0 --settle-low 0 --noise-observations --no-fine --no-cpu-baseline --no-extra-records"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $PROF > $OUT/stats.log 2>&1
 python $R/tools/gap_analysis.py $OUT/stats 17 44 > $OUT/gaps.txt 2>&1            # GPU busy / idle of the clean pass (iterations 17..43 of 75) and where the idle time sits
 python $R/tools/iteration_timeline.py $OUT/stats 45 > $OUT/timeline.txt 2>&1   # one iteration of the clean pass: segments of GPU activity and the gaps between them
 find $OUT/stats -name "*kernel_trace.csv" -delete
 # 3. HBM traffic of the layer GEMMs: FETCH_SIZE and WRITE_SIZE in separate passes, + the calibration launches
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python $R/bench.py --steps 6 --warmup 0 --settle 0 --settle-low 0 --noise-observations --no-fine --no-cpu-baseline --no-bf16x3-record --no-extra-records --no-sdf-throughput --shape-log $OUT/pmc_shapes_$C.json > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python $R/bench.py --steps 6 --warmup 0 --settle 0 --settle-low 0 --noise-observations --no-fine --no-cpu-baseline --no-extra-records --no-sdf-throughput --shape-log $OUT/pmc_shapes_$C.json > $OUT/pmc_$C.log 2>&1
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/cal_$C -- python $R/tools/pmc_calibrate.py > $OUT/cal_$C.log 2>&1
   python - "$OUT" "$C" <<'PY'
 import csv, glob, sys, json, collections

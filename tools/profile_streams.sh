@@ -6,7 +6,7 @@ R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python $R/bench.py --steps 12 --warmup 3 --settle 0 --settle-low 8 --no-gemm-events --no-fine --no-cpu-baseline --no-bf16x3-record --no-sdf-throughput ${PROFILE_EXTRA:-} > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python $R/bench.py --steps 12 --warmup 3 --settle 0 --settle-low 8 --no-gemm-events --no-fine --no-cpu-baseline --no-sdf-throughput ${PROFILE_EXTRA:-} > $OUT/run.log 2>&1
 python $R/tools/stream_view.py $OUT/trace 16 > $OUT/streams.txt 2>&1
 python $R/tools/iteration_timeline.py $OUT/trace 16 > $OUT/timeline.txt 2>&1
 find $OUT/trace -name "*kernel_trace.csv" -delete

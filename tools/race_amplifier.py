@@ -34,7 +34,7 @@ configs = [("baseline", {}), ("main held 6 ms after the fork", {"SR_DEBUG_DELAY"
            ("refiner held 10 ms", {"SR_DEBUG_DELAY": "refiner_start:10"}), ("aux held 10 ms", {"SR_DEBUG_DELAY": "aux_after_wait:10"}),
            ("main held 10 ms before it joins the side streams", {"SR_DEBUG_DELAY": "main_before_join:10"}), ("every weight-gradient launch held 1 ms", {"SR_DEBUG_TN_DELAY_MS": "1"})]
 base = None
-for mode in (os.environ.get("SR_GEMM", "f32"),):
+for mode in ("f32",):
     for name, env in configs:
         out = f"/tmp/race_{len(name)}.pt"
         r = subprocess.run([sys.executable, "-c", CHILD, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
