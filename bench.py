@@ -379,6 +379,10 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
     rccl = srdist.describe()                                  # (a collective: every rank calls it)
+    if world > 1 and rccl.get("devices") and os.environ.get("SR_ALL_RANKS_ON_DEVICE0") != "1" and str(rccl.get("backend", "")).startswith("rccl"):
+        ids = {(d["pci_bus_id"], d["pci_device_id"], d["device_index"]) for d in rccl["devices"]}
+        if len(ids) != world:                                 # an N-GPU record must be N ranks on N different devices
+            raise SystemExit(f"--gpus {world}: the ranks sit on {len(ids)} distinct device(s): {rccl['devices']}")
     if args.simulate_world > 1:
         if world != 1:
             raise SystemExit("--simulate-world is a single-GPU measurement")

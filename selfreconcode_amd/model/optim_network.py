@@ -158,6 +158,9 @@ class OptimNetwork(nn.Module):
                     # (also at a forced world size of 1 -- SR_DIST_FORCE_INIT, the RCCL self-test: one chunk, one all-gather)
                     # N ranks: every rank queries its contiguous chunk of the list and one all-gather hands every rank the same
                     # values (bit-identical replicas of the volume -> identical, deterministic marching cubes on every rank)
+                    # (every rank must enter this collective with the same M: a replica whose volume differs in one sign has another
+                    # candidate list -- fail loudly on all ranks instead of hanging in a mismatched all-gather)
+                    srdist.assert_same_across_ranks(M, "seg3d query count of this level")
                     lo, hi, per = srdist.chunk_bounds(M, rank, world)
                     mine = self.sdf.forward(pts[lo:hi].contiguous(), ratio, sdf_only=True).reshape(-1) if hi > lo else pts.new_zeros(0)
                     return srdist.all_gather_chunks(mine, M, per).reshape(1, 1, -1)

@@ -104,3 +104,63 @@ def test_two_rank_gradient_allreduce_matches_full_batch():
         torch.testing.assert_close(tv, torch.full((5, 3), 1.5))
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)                           # bit-identical on both ranks -> replicas stay in lock-step
+
+
+def _worker4(rank, world, port, out):
+    """Four ranks, ragged everything: V % R != 0 for the sharded template term, query lists shorter than the group, frames that do not
+    divide over the ranks evenly, a rank with no frame at all, and the per-level count check that guards the all-gather."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from selfreconcode_amd import dist as srdist
+    r, w, dev = srdist.init_from_env("cpu")
+    assert (r, w) == (rank, world)
+    # sharded template term: vertices r::R of V = 4k+1, 4k+2, 4k+3 and V < R
+    for V in (41, 42, 43, 3):
+        f = torch.randn(V, generator=torch.Generator().manual_seed(V))
+        mine = f[rank::world]
+        part = (mine.abs().sum() if mine.numel() else f.new_zeros(())) * (float(world) / V)
+        tot = part.clone(); dist.all_reduce(tot); tot /= world
+        assert abs(float(tot) - float(f.abs().mean())) < 1e-6, (V, float(tot))
+    # remesh query chunks: lengths that leave the last ranks a short or EMPTY chunk
+    for n in (4096 * 4 + 5, 9, 3, 1):
+        full = torch.arange(n, dtype=torch.float32) * 0.25 - 1.0
+        lo, hi, per = srdist.chunk_bounds(n, rank, world)
+        assert 0 <= lo <= hi <= n and per * world >= n
+        got = srdist.all_gather_chunks(full[lo:hi].clone(), n, per)
+        assert torch.equal(got, full), n
+    # the count check in front of the gather: equal counts pass, a replica that drifted by one query raises on EVERY rank
+    srdist.assert_same_across_ranks(12345, "seg3d query count")
+    try:
+        srdist.assert_same_across_ranks(12345 + (1 if rank == 2 else 0), "seg3d query count")
+        raised = False
+    except RuntimeError:
+        raised = True
+    assert raised
+    # frames: 6 frames over 4 ranks -> 2, 2, 1, 1; 3 frames -> the last rank has none and still joins every collective with zeros
+    assert [srdist.shard_frames(torch.arange(6), r_, world).numel() for r_ in range(world)] == [2, 2, 1, 1]
+    mine = srdist.shard_frames(torch.arange(3), rank, world)
+    p = torch.nn.Parameter(torch.zeros(3, 2))
+    if mine.numel():
+        (p[mine] - 1.0).pow(2).sum().backward()
+    bucket = srdist.GradBucket([p])
+    bucket.all_reduce_mean()
+    tv = None if mine.numel() else torch.zeros(5, 3)
+    tv = srdist.all_reduce_mean_(torch.full((5, 3), float(rank)) if tv is None else tv)
+    out.put((rank, p.grad.numpy().copy(), tv.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_four_ranks_ragged_shards_and_the_count_guard():
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = torch.full((3, 2), -2.0 / 4)                    # d/dp (p - 1)^2 at 0 = -2 on the three owning ranks, mean over 4 ranks
+    for rank, g, tv in res:
+        torch.testing.assert_close(torch.from_numpy(g), want)
+        torch.testing.assert_close(torch.from_numpy(tv), torch.full((5, 3), (0 + 1 + 2 + 0) / 4.0))
