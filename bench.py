@@ -470,6 +470,10 @@ def main():
         "value": round(args.steps * world * FR / FR_REF / elapsed, 4), "unit": "iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_rec["ms_per_step"],
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "methodology": {"version": 2, "since": "round 4",
+                        "note": "version 2 times the coarse stage at the learning rate config.conf runs it at (1e-4: 7-22 % of the rays converge); rounds 2-3 (version 1) "
+                                "timed it at the late MultiStepLR rate (~75 % converge: a heavier colour / normal branch) -- compare BENCH_r02 / r03 with "
+                                "`late_schedule_lr.ms_per_step` of this line, not with `value`"},
         "config": {"workload": f"configs[1]: female-3-casual-like 540x540, {args.stage} stage = {epochs}, Adam lr {lr_timed:.3g}, {FR} frame(s) x {RAYS} rays per rank, full iteration "
                                "(template deform + K=50 point-silhouette mask loss + template SGD, mesh rasteriser + seeds + Newton refiner, "
                                "eikonal/offset/def-regu/DCT/colour/normal, backward, implicit-grad propagation, Adam, one remesh in the timed window)"

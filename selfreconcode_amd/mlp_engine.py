@@ -253,8 +253,10 @@ def _bias_segments(b0, R, group):
 # before flush_param_grads, which joins the stream); all weight-gradient launches share ONE stream, so the accumulation order into
 # a buffer is the program order -- results are bit-identical to the one-stream schedule.
 TN_SIDE_STREAM = os.environ.get("SR_TN_STREAM", "1") != "0"
-TN_HALF_SLABS = TN_SIDE_STREAM if os.environ.get("SR_TN_HALF_SLABS") is None else os.environ["SR_TN_HALF_SLABS"] != "0"   # deferred weight gradients use half the row slabs (see _gemm_tn); a switch of its own so that the
-                                      # stream can be toggled without changing the summation order
+# Row slabs of the deferred weight-gradient launches: all of them (two workgroups per CU) since round 5 -- with the ray branch and the
+# template term's backward moved under the refiner the weight-gradient stream is what the tail of the big backward waits for (45.0 ->
+# 44.2 ms / iteration); SR_TN_HALF_SLABS=1 restores round 3's half count (one workgroup per CU next to the other stream's two).
+TN_HALF_SLABS = os.environ.get("SR_TN_HALF_SLABS", "0") != "0"
 _TN_STREAMS = {}
 _TN_PENDING = set()
 

@@ -43,6 +43,12 @@ SPLIT_SAMPLE_TERMS = os.environ.get('SR_SPLIT_SAMPLE_TERMS', '0') != '0'    # se
 # stream, and the stand-ins' gradients are handed to the real leaves when the two streams join (OptimNetwork._finish_ray_branch).
 # Every parameter gradient is the same sum of the same terms; off = one backward of the total loss, as the reference writes it.
 EAGER_RAY_BRANCH = os.environ.get('SR_EAGER_RAY_BRANCH', '1') != '0'
+# The template term pc_weight * mean |f(TmpVs)| (network.py:690-694) does not depend on the refiner, and its backward -- an SDF reverse
+# sweep over all V vertices, ~5 ms of large launches -- is as independent of it as its forward.  Back-propagated at once (a second inner
+# backward of computeTmpPcLoss) those launches run UNDER the refiner's chain of ~230 dependent small launches instead of after the
+# join: the refiner used to end ~2.5 ms after the main stream had drained, with nothing but its last few-hundred-row phases on the
+# machine.  Same gradient, same sum; the returned loss carries the term's value.
+EAGER_TEMPLATE_TERM = os.environ.get('SR_EAGER_TEMPLATE_TERM', '1') != '0'
 _SIDE_STREAMS = {}
 
 
@@ -389,6 +395,7 @@ class OptimNetwork(nn.Module):
         self._mark('template deformed')
         if debug is not None:
             debug['defTmpVs'] = defTmpVs.detach().clone()
+            debug['TmpVs'] = self.TmpVs.detach().clone()          # (the template this call deforms: after a remesh, before its SGD step)
         self.info['pc_loss'] = {}
 
         # Two streams.  The template branch (silhouette, mask loss, its backward, the template SGD step, |f(TmpVs)|) is a few
@@ -478,6 +485,7 @@ class OptimNetwork(nn.Module):
                 r1.record(rstream); rev.append((r0, r1))
             refined = torch.cuda.Event()
             refined.record(rstream)
+            self._mark('refiner done (its stream)')
         self._mark('refiner issued')
         aux = self._side_stream(device, 1)
         with torch.cuda.stream(aux), torch.no_grad():
@@ -641,6 +649,7 @@ class OptimNetwork(nn.Module):
                     extra.backward()                     # inner backward: TmpPs.grad, the stand-ins' gradients, the deferred weight gradients
                     ctx['bwd_done'] = torch.cuda.Event()
                     ctx['bwd_done'].record(rb)
+                    self._mark('ray branch backward done (its stream)')
                     self._ray_ctx = ctx
                     if on_rb_side:
                         main.wait_event(known)           # (the VALUE of the two terms joins the returned loss; the forward of the branch is
@@ -818,7 +827,12 @@ class OptimNetwork(nn.Module):
             mnfld_pred = self.sdf(self.TmpVs.detach(), ratio, sdf_only=True).view(-1)
             sdf_loss = (mnfld_pred + self.sdfShrinkRadius).abs().mean()
         self.info['pc_loss_sdf'] = sdf_loss.detach()
-        return sdf_loss * (self.conf.get_float('pc_weight.weight') if 'pc_weight' in self.conf else 60.)
+        term = sdf_loss * (self.conf.get_float('pc_weight.weight') if 'pc_weight' in self.conf else 60.)
+        if EAGER_TEMPLATE_TERM and term.requires_grad:
+            term.backward()
+            self._mark('tb: template term back-propagated')
+            term = term.detach()
+        return term
 
     # ------------------------------------------------------------------ implicit differentiation (a15)
     def propagateTmpPsGrad(self, frame_ids, ratio, overlap=None):
@@ -897,5 +911,6 @@ class OptimNetwork(nn.Module):
                     if t.requires_grad and t.is_leaf and id(t) not in seen:
                         seen.add(id(t)); leaves.append(t)
                 torch.autograd.backward(outs, cots, inputs=leaves)
+            self._mark('implicit-gradient pass done (its stream)')
         self._finish_ray_branch()
         mlp_engine.flush_param_grads()       # last gradient producer of the step (no-op unless deferred mode is on)

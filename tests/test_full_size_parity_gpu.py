@@ -304,6 +304,18 @@ def test_full_size_iteration_vs_the_references_own_run(golden, stage):
     corr, flips = l1_sign_correction(net, g["f_moved_x1024"].float() / 1024., float(g["pc_weight"]), RATIO)
     print("template L1 term: %d of %d vertices change sign against the reference (largest |f| among them %.1e)" % (flips[0], V0.shape[0], flips[1]))
     res = _collect_step(net, ds, V0, loss, nets)
+    # the SDF gradients as they ARE, before the sign correction, against the reference's digests / slices (reported, not asserted: the
+    # flipped vertices' contribution is a property of float32, not of this implementation -- see tests/test_trajectory_full_gpu.py)
+    uncorrected = {}
+    for k_, (name, p_) in enumerate(sdf.named_parameters()):
+        key = "sdf." + name
+        gq = res[key].detach().double().cpu().reshape(-1)
+        want = g["d_" + key]
+        nb = max(float(want[0]), 1e-30)
+        errs = [abs(float(gq.norm()) - float(want[0])) / nb] + [abs(float(gq @ fx.det_tensor((gq.numel(),), s_ + 100 * k_, 1.0, torch.float64)) - float(w_)) / nb for s_, w_ in zip(PROJ_SEEDS, want[1:])]
+        sl, rs = slice_of(res[key]).double().cpu().reshape(-1), g["s_" + key].double().reshape(-1)
+        uncorrected[key] = {"digest_errors_rel": errs, "slice_max_err_over_max": float((sl - rs).abs().max()) / max(float(rs.abs().max()), 1e-30),
+                            "slice_rel_l2": float((sl - rs).norm()) / max(float(rs.norm()), 1e-30)}
     for name in corr:
         res["sdf." + name] = res["sdf." + name] + corr[name]
 
@@ -382,6 +394,7 @@ def test_full_size_iteration_vs_the_references_own_run(golden, stage):
                           "refiner": {"flags_equal": float((ok.cpu() == ref_ok).float().mean()), "points_within_2e-5": frac(2e-5), "points_within_5e-4": frac(5e-4),
                                       "points_max": float(dev_p.max()), "accepted_on_both_sides": int(both.sum())},
                           "l1_sign_flips": {"vertices": flips[0], "largest_abs_f_among_them": flips[1]},
+                          "sdf_gradients_WITHOUT_the_sign_correction": uncorrected,
                           "achieved": {k: list(v) for k, v in rep.worst.items()}, "bounds": bounds, "noise_cap_multiplier_of_base": NOISE_CAP,
                           "failed": list(rep.bad),
                           "legend": "achieved[name] = (max-error / max|reference|, relative L2) for tensors, (|norm|, projection 1, projection 2 errors relative to "
