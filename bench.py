@@ -58,26 +58,41 @@ sys.path.insert(0, ROOT)
 STAGES = {"coarse": dict(frames=3, rays=2048), "fine": dict(frames=1, rays=6144)}
 
 
-def gpu_sensors():
-    """Shader clock (MHz) and socket power (W) of the first amdgpu device from sysfs -- two small file reads, cheap enough to take INSIDE
-    the timed window while the GPU is loaded (rocm-smi is a Python process of its own: 0.3 s of host CPU per sample).  None where the
-    files do not exist (containers without /sys/class/drm)."""
+def gpu_sensors(device_index=0):
+    """Shader clock (MHz) and socket power (W) of THIS process's GPU from sysfs -- two small file reads, cheap enough to take INSIDE the
+    timed window while the GPU is loaded (rocm-smi is a Python process of its own: 0.3 s of host CPU per sample).  The card is found by
+    the PCI bus id torch reports (a box has several GPUs and the visible one is not card0); if that fails, the busiest card (highest
+    current clock) is reported and marked.  None where the files do not exist (containers without /sys/class/drm)."""
     import glob
-    out = {}
+
+    def read(card):
+        out = {}
+        for line in open(os.path.join(card, "pp_dpm_sclk")):
+            if "*" in line:
+                out["sclk_mhz"] = int("".join(c for c in line.split(":")[1] if c.isdigit()))
+        for name in ("power1_average", "power1_input"):
+            hs = glob.glob(os.path.join(card, "hwmon", "hwmon*", name))
+            if hs:
+                out["power_w"] = round(int(open(hs[0]).read().strip()) / 1e6, 1)
+                break
+        return out
     try:
-        for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))[:1]:
-            for line in open(f):
-                if "*" in line:
-                    out["sclk_mhz"] = int("".join(c for c in line.split(":")[1] if c.isdigit()))
-            for name in ("power1_average", "power1_input"):
-                for h in glob.glob(os.path.join(os.path.dirname(f), "hwmon", "hwmon*", name)):
-                    out["power_w"] = round(int(open(h).read().strip()) / 1e6, 1)
-                    break
-                if "power_w" in out:
-                    break
+        cards = sorted(d for d in glob.glob("/sys/class/drm/card*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
+        if not cards:
+            return None
+        want = None
+        try:
+            want = int(getattr(torch.cuda.get_device_properties(device_index), "pci_bus_id"))
+        except Exception:
+            pass
+        for d in cards:
+            addr = os.path.basename(os.path.realpath(d))            # 0000:bb:dd.f
+            if want is not None and len(addr.split(":")) == 3 and int(addr.split(":")[1], 16) == want:
+                return dict(read(d), card=os.path.basename(os.path.dirname(d)), matched_by="pci_bus_id") or None
+        best = max((read(d) for d in cards), key=lambda r: r.get("sclk_mhz", 0))
+        return dict(best, matched_by="highest clock of %d cards" % len(cards)) or None
     except (OSError, ValueError, IndexError):
-        pass
-    return out or None
+        return None
 
 
 def _eager_ray_branch():
@@ -526,7 +541,7 @@ def main():
                      "note": "event pairs are recorded in a SECOND pass over the same K steps (ms_per_step_instrumented); the headline pass carries no events",
                      "traffic": None},
     }
-    for name in ("r04_pmc_gemm_nt.json", "r03_pmc_gemm_nt.json", "r02_pmc_gemm_nt.json", "r01_pmc_gemm_nt.json"):       # PMC passes cannot run inside this process; latest committed collection
+    for name in ("r05_pmc_gemm_nt.json", "r04_pmc_gemm_nt.json", "r03_pmc_gemm_nt.json", "r02_pmc_gemm_nt.json", "r01_pmc_gemm_nt.json"):       # PMC passes cannot run inside this process; latest committed collection
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.isfile(pmc):
             with open(pmc) as fh:

@@ -103,10 +103,13 @@ def test_compute_tmp_pc_loss_vs_oracle():
         close(dict(tr.named_parameters())[n].grad, sc.tr[n].grad, 1e-3, 2e-3, "deformer " + n)
     close(ds.conds[0].grad[fids], sc.dcond.grad[fo], 1e-3, 2e-3, "d_cond"); close(ds.poses.grad[fids], sc.poses.grad[fo], 1e-3, 2e-3, "poses")
     close(ds.trans.grad[fids], sc.trans.grad[fo], 1e-3, 2e-3, "trans")
-    # outer backward of the |f(TmpVs)| term
-    for t in net.sdf.parameters():
-        t.grad = None
-    out.backward(); mlp_engine.flush_param_grads(); outo.backward()
+    # backward of the |f(TmpVs)| term: the reference leaves it to the outer backward; here it is back-propagated where it is computed
+    # (optim_network.EAGER_TEMPLATE_TERM: the returned term is then a value) -- the SDF has no other gradient at this point either way
+    if out.requires_grad:
+        for t in net.sdf.parameters():
+            t.grad = None
+        out.backward()
+    mlp_engine.flush_param_grads(); outo.backward()
     for n in ("lin0.weight_v", "lin4.weight_g", "lin8.weight_v", "lin8.bias", "lin6.bias"):
         close(dict(net.sdf.named_parameters())[n].grad, sc.sdf[n].grad, 1e-3, 1e-3, "sdf " + n)
 

@@ -14,7 +14,7 @@ if int(os.environ.get('SR_HP_SIM_WORLD', '0')) > 1:
     from selfreconcode_amd import dist as _srdist
     _srdist.simulate_world((0, int(os.environ['SR_HP_SIM_WORLD'])))
 dev = torch.device('cuda:0')
-net, ds, conf = build_synthetic_scene(device=dev, frame_num=64, stage='coarse', consistent_masks=False)
+net, ds, conf = build_synthetic_scene(device=dev, frame_num=64, stage=os.environ.get('SR_HP_STAGE', 'coarse'), consistent_masks=False)
 params = [p for p in net.parameters() if p.requires_grad]
 mlp_engine.set_deferred_param_grads(True)
 opt = FusedAdam([{'params': ds.learnable_weights()}, {'params': params}], lr=float(os.environ.get('SR_HP_LR', '1e-4')))
@@ -28,7 +28,7 @@ def step(mark=False):
     f = torch.arange(FR * it % 56, FR * it % 56 + FR, device=dev)
     t0 = time.perf_counter()
     opt.zero_grad(set_to_none=True)
-    loss = net(ds.batch(f), 2048, ratio, f)
+    loss = net(ds.batch(f), int(os.environ.get('SR_HP_RAYS', '2048')), ratio, f)
     t1 = time.perf_counter()
     loss.backward()
     net._mark('backward issued')
