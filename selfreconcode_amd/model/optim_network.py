@@ -622,6 +622,7 @@ class OptimNetwork(nn.Module):
                 # the stand-ins' gradients goes through them, after the streams have joined
                 dep = [t for t in self.dataset.get_grad_parameters(frame_ids, device)] + (list(self.dataset.get_camera_parameters(N, device)[:4]) if cam_learn else [])
             with torch.cuda.stream(rb):
+                self._debug_delay('ray_branch_start')
                 if eager:
                     with torch.no_grad():
                         vals = list(self.dataset.get_grad_parameters(frame_ids, device)) + (list(self.dataset.get_camera_parameters(N, device)[:4]) if cam_learn else [])
@@ -674,6 +675,8 @@ class OptimNetwork(nn.Module):
         main, rb = ctx['main'], ctx['stream']
         if final:
             self._ray_ctx = None
+            with torch.cuda.stream(main):
+                self._debug_delay('main_before_ray_join')
         if rb is not main:
             main.wait_stream(rb) if final else main.wait_event(ctx['bwd_done'])
         outs, grads = [], []
@@ -855,6 +858,7 @@ class OptimNetwork(nn.Module):
         # on that stream with the branch's stand-ins of the per-frame / camera tensors; called on its own it uses the real ones.
         with torch.cuda.stream(ctx['stream']) if ctx is not None else contextlib.nullcontext():
             if ctx is not None:
+                self._debug_delay('ray_branch_propagate_start')
                 (poses, trans, d_cond), cameras = ctx['frame'], ctx['cameras']
             else:
                 poses, trans, d_cond, _ = self.dataset.get_grad_parameters(frame_ids, device)

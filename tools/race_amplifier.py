@@ -32,7 +32,11 @@ torch.save(outs, sys.argv[1])
 import torch
 configs = [("baseline", {}), ("main held 6 ms after the fork", {"SR_DEBUG_DELAY": "main_after_fork:6"}), ("side held 8 ms after its wait", {"SR_DEBUG_DELAY": "side_after_wait:8"}),
            ("refiner held 10 ms", {"SR_DEBUG_DELAY": "refiner_start:10"}), ("aux held 10 ms", {"SR_DEBUG_DELAY": "aux_after_wait:10"}),
-           ("main held 10 ms before it joins the side streams", {"SR_DEBUG_DELAY": "main_before_join:10"}), ("every weight-gradient launch held 1 ms", {"SR_DEBUG_TN_DELAY_MS": "1"})]
+           ("main held 10 ms before it joins the side streams", {"SR_DEBUG_DELAY": "main_before_join:10"}),
+           ("ray branch held 12 ms at its start (the main stream runs the sampled terms and the big backward meanwhile)", {"SR_DEBUG_DELAY": "ray_branch_start:12"}),
+           ("implicit-gradient pass held 12 ms on the ray branch's stream", {"SR_DEBUG_DELAY": "ray_branch_propagate_start:12"}),
+           ("main held 8 ms before it joins the ray branch", {"SR_DEBUG_DELAY": "main_before_ray_join:8"}),
+           ("ray branch AND every weight-gradient launch held", {"SR_DEBUG_DELAY": "ray_branch_start:6", "SR_DEBUG_TN_DELAY_MS": "1"}), ("every weight-gradient launch held 1 ms", {"SR_DEBUG_TN_DELAY_MS": "1"})]
 base = None
 for mode in ("f32",):
     for name, env in configs:
