@@ -51,10 +51,15 @@ LR = 1e-4
 DRAW_BASE = 29000
 EVAL_FRAMES = [2, 11, 19, 30]
 RES_COARSE = [(15, 21, 9), (29, 41, 17), (57, 81, 33), (113, 161, 65), (225, 321, 129)]       # train.py:29-37
+RES_FINE = [(21, 27, 15), (41, 53, 29), (81, 105, 57), (161, 209, 113), (321, 417, 225)]        # train.py:45-51
+# `--stage fine`: the stage 189 of the reference's 201 epochs run in -- 1 frame x 6144 rays per iteration (config.conf:43-48,113), loss_fine, a
+# 173 402-vertex template, remesh on 321 x 417 x 225, Adam at 1e-4 * 0.333^3 (the MultiStepLR value of epochs 80-129) -> trajectory_full_fine.npz
+STAGE = {"coarse": dict(N=3, res=RES_COARSE, lr=1e-4, radius=0.006, base=29000, remesh=30, name="trajectory_full.npz"),
+         "fine": dict(N=1, res=RES_FINE, lr=1e-4 * 0.333 ** 3, radius=0.0041, base=39000, remesh=120, name="trajectory_full_fine.npz")}
 
 
-def frames_of(k, F):
-    return [(7 + 3 * k) % F, (21 + 5 * k) % F, (30 + 7 * k) % F]
+def frames_of(k, F, N=3):
+    return [(7 + 3 * k) % F, (21 + 5 * k) % F, (30 + 7 * k) % F][:N]
 
 
 def ratio_of(k):
@@ -78,14 +83,16 @@ def observations(fids, H, W):
 
 
 class Draws(gt.Draws):
+    base = DRAW_BASE
+
     def rand(self, *size, **kw):
         shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
         self.calls.append(('rand', shape))
-        return fx.det_tensor(shape, DRAW_BASE + 16 * self.k + len(self.calls) - 1, 0.5) + 0.5
+        return fx.det_tensor(shape, self.base + 16 * self.k + len(self.calls) - 1, 0.5) + 0.5
 
     def randn_like(self, x, **kw):
         self.calls.append(('randn_like', tuple(x.shape)))
-        return fx.det_normal(tuple(x.shape), DRAW_BASE + 16 * self.k + len(self.calls) - 1)
+        return fx.det_normal(tuple(x.shape), self.base + 16 * self.k + len(self.calls) - 1)
 
 
 class MaskRender(gt.MaskRender):
@@ -108,12 +115,15 @@ def main():
     if "--k" in sys.argv:
         kk = int(sys.argv[sys.argv.index("--k") + 1])
     twin = "--twin" in sys.argv
+    stage = sys.argv[sys.argv.index("--stage") + 1] if "--stage" in sys.argv else "coarse"
+    cfg = STAGE[stage]
+    Draws.base = cfg["base"]
     noray = "--no-ray-terms" in sys.argv        # (diagnostics) colour / normal weights 0: no ray branch, no implicit-gradient pass -> trajectory_full_noray.npz
     cover_only = "--cover" in sys.argv          # re-run up to the remesh and merge the rasterised silhouettes of that iteration into the fixture (bit-packed)
     torch.set_num_threads(os.cpu_count())
     t_start = time.perf_counter()
     f64 = "--f64" in sys.argv                   # (diagnostics) the same modules evaluated in double on the same float32-representable inputs; prints only
-    net, ds, _, _, q, V0, faces = gf.build("coarse", dtype=torch.float64 if f64 else torch.float32)
+    net, ds, _, _, q, V0, faces = gf.build(stage, dtype=torch.float64 if f64 else torch.float32)
     # The coarse-stage fixture's template sits ON the zero set of the initial SDF by construction (one-iteration parity wants converging
     # rays), with 4e-3 offsets that leave ~0.1 % of the vertices at |f| < 3e-5 -- and a handful below the 3e-7 to which any float32
     # evaluation of f is reproducible.  The L1 template term's gradient is sign(f) per vertex and Adam's first steps are sign steps, so
@@ -135,9 +145,10 @@ def main():
         net.conf = gi.DictConf(dict(gi.LOSS_COARSE, color_weight=0., normal_weight=-0.1))
     H = W = 540
     F = ds.frame_num
-    N = 3
+    N = cfg["N"]
+    SPX = 2048                                   # (the fine stage's loss_fine carries sample_pix_num = 6144, which overrides it: network.py:520)
     net.maskRender = MaskRender(H, W, faces)
-    net.engine = ref.MCAcc.Seg3dLossless(query_func=None, b_min=fx.LBS_BMIN, b_max=fx.LBS_BMAX, resolutions=RES_COARSE, align_corners=False, balance_value=0.0,
+    net.engine = ref.MCAcc.Seg3dLossless(query_func=None, b_min=fx.LBS_BMIN, b_max=fx.LBS_BMAX, resolutions=cfg["res"], align_corners=False, balance_value=0.0,
                                          device='cpu', visualize=False, debug=False, use_cuda_impl=False, faster=False)
     remeshed = {}
 
@@ -157,21 +168,21 @@ def main():
         def vertex_face_indices(self):
             return -np.ones((self.n, 1), np.int64)
     ref.network.om = types.SimpleNamespace(TriMesh=_TriMesh)
-    net.forward_time, net.remesh_intersect, net.remesh_time = 30 - REMESH_AT, 30, 0.          # one remesh in the window: at the call with index REMESH_AT
+    net.forward_time, net.remesh_intersect, net.remesh_time = cfg["remesh"] - REMESH_AT, cfg["remesh"], 0.          # one remesh in the window: at the call with index REMESH_AT
     learn = [ds.conds[0], ds.conds[1], ds.focal, ds.princ, ds.T, ds.poses, ds.trans]          # dataset.learnable_weights(): codes, camera, poses, trans
-    optimizer = torch.optim.Adam([{'params': learn}, {'params': [p for p in net.parameters() if p.requires_grad]}], lr=LR)
+    optimizer = torch.optim.Adam([{'params': learn}, {'params': [p for p in net.parameters() if p.requires_grad]}], lr=cfg["lr"])
     gtm1 = gf.mask_image(1, H, W)
 
     real_rand, real_randn_like = torch.rand, torch.randn_like
-    out = dict(q=q.view(-1), nudge_idx=nudge_idx.to(torch.int32), HW=np.array([H, W]), SP=np.array(2048), K=np.array(kk), remesh_at=np.array(REMESH_AT), frame_num=np.array(F), lr=np.array(LR),
-               radius=np.array(0.006), ang_thr=np.array(net.angThred), res=np.array(RES_COARSE), eval_frames=np.array(EVAL_FRAMES), lbs_shape=np.array([65, 225, 129]),
-               n_cube=np.array(gf.STAGES["coarse"]["n_cube"]), draw_base=np.array(DRAW_BASE))
+    out = dict(q=q.view(-1), nudge_idx=nudge_idx.to(torch.int32), HW=np.array([H, W]), SP=np.array(SPX), K=np.array(kk), remesh_at=np.array(REMESH_AT), remesh_intersect=np.array(cfg["remesh"]), frame_num=np.array(F), lr=np.array(cfg["lr"]), frames_per_iteration=np.array(N),
+               radius=np.array(cfg["radius"]), ang_thr=np.array(net.angThred), res=np.array(cfg["res"]), eval_frames=np.array(EVAL_FRAMES), lbs_shape=np.array([65, 225, 129]),
+               n_cube=np.array(gf.STAGES[stage]["n_cube"]), draw_base=np.array(cfg["base"]))
     names = ('grad_loss', 'def_loss', 'dct_loss', 'color_loss', 'normal_loss', 'offset_loss', 'pc_loss_sdf')
     curve = {n: [] for n in names + ('mask_loss', 'defconst_loss', 'total')}
     ray_counts, draw_shapes, vcount, maskE_it, seconds = [], [], [], [], []
     for k in range(kk):
         t0 = time.perf_counter()
-        fids = torch.tensor(frames_of(k, F))
+        fids = torch.tensor(frames_of(k, F, N))
         draws = Draws(k)
         torch.rand, torch.randn_like = draws.rand, draws.randn_like
         try:
@@ -181,7 +192,7 @@ def main():
                 obs = {k_: v_.double() for k_, v_ in obs.items()}
                 torch.Tensor.float, real_float = (lambda self, *a, **kw: self.to(torch.float64)), torch.Tensor.float
             try:
-                loss = net(obs, 2048, ratio_of(k), fids)
+                loss = net(obs, SPX, ratio_of(k), fids)
             finally:
                 if f64:
                     torch.Tensor.float = real_float
@@ -205,7 +216,7 @@ def main():
         if 'V' in remeshed and "remesh_V" not in out:
             out["remesh_V"], out["remesh_nV"], out["remesh_nF"], out["remesh_k"] = remeshed['V'][::11].clone(), np.array(remeshed['V'].shape[0]), np.array(remeshed['F'].shape[0]), np.array(k)
         seconds.append(time.perf_counter() - t0)
-        print(k, frames_of(k, F), "loss %.6f" % float(loss), "rays", info['rayInfo'], "V", net.TmpVs.shape[0], "maskE", np.round(maskE_it[-1], 4).tolist(),
+        print(k, frames_of(k, F, N), "loss %.6f" % float(loss), "rays", info['rayInfo'], "V", net.TmpVs.shape[0], "maskE", np.round(maskE_it[-1], 4).tolist(),
               "%.1f s" % seconds[-1], flush=True)
     if f64:
         print("float64 evaluation: total loss per iteration", [round(v, 6) for v in curve['total']], "pc_loss_sdf", [round(v, 6) for v in curve['pc_loss_sdf']])
@@ -230,25 +241,25 @@ def main():
     out["final_cam"] = torch.cat([ds.focal.detach(), ds.princ.detach(), ds.T.detach()])
     conv = {k_: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k_, v in out.items()}
     if cover_only:
-        main = dict(np.load(os.path.join(OUT, "trajectory_full.npz")))
+        main = dict(np.load(os.path.join(OUT, cfg["name"])))
         # (the reference on CPU is not bit-reproducible run to run -- multi-threaded reductions: after ~9 iterations a re-run accepts one ray
         # more or less; the silhouettes agree to a few pixels)
         dev = float(np.abs(main["maskE_it"][:kk] - conv["maskE_it"]).max())
         print("re-run against the fixture: max |maskE difference| %.5f" % dev)
         assert dev < 5e-3, "the re-run did not reproduce the fixture"
         main["cover_at_remesh"] = conv["cover_at_remesh"]
-        np.savez_compressed(os.path.join(OUT, "trajectory_full.npz"), **main)
-        print("merged cover_at_remesh into trajectory_full.npz")
+        np.savez_compressed(os.path.join(OUT, cfg["name"]), **main)
+        print("merged cover_at_remesh into", cfg["name"])
         return
     if twin:                                                             # merged into the main fixture
-        main = dict(np.load(os.path.join(OUT, "trajectory_full.npz")))
+        main = dict(np.load(os.path.join(OUT, cfg["name"])))
         main.update(twin_maskE_it=conv["maskE_it"], twin_remesh_nV=conv.get("remesh_nV", np.array(-1)), twin_L_total=conv["L_total"], twin_ray_counts=conv["ray_counts"])
-        np.savez_compressed(os.path.join(OUT, "trajectory_full.npz"), **main)
-        print("merged the twin into trajectory_full.npz: max |maskE - twin| before the remesh %.5f, from it on %.4f; remesh vertices %d against %d" % (
+        np.savez_compressed(os.path.join(OUT, cfg["name"]), **main)
+        print("merged the twin into " + cfg["name"] + ": max |maskE - twin| before the remesh %.5f, from it on %.4f; remesh vertices %d against %d" % (
             np.abs(main["maskE_it"][:REMESH_AT] - conv["maskE_it"][:REMESH_AT]).max(), np.abs(main["maskE_it"][REMESH_AT:kk] - conv["maskE_it"][REMESH_AT:kk]).max(),
             int(main["remesh_nV"]), int(conv.get("remesh_nV", -1))))
         return
-    name = "trajectory_full_noray.npz" if noray else ("trajectory_full.npz" if kk == K else f"trajectory_full_k{kk}.npz")
+    name = "trajectory_full_noray.npz" if noray else (cfg["name"] if kk == K else f"trajectory_full_{stage}_k{kk}.npz")
     np.savez_compressed(os.path.join(OUT, name), **conv)
     rc = np.array(ray_counts, dtype=np.float64)
     print("wrote", name, os.path.getsize(os.path.join(OUT, name)), "bytes; total %.0f s; maskE" % (time.perf_counter() - t_start), maskE.tolist())
