@@ -50,6 +50,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (multi-process GPU work on this pool: the host driver only supports dmabuf IPC; must be set before HIP initialises)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

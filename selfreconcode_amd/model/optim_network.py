@@ -88,6 +88,7 @@ class OptimNetwork(nn.Module):
         self.info = {}
         self.dataset = None
         self.dctnull = None
+        self._ray_ctx = None                  # an open ray branch (EAGER_RAY_BRANCH): closed by propagateTmpPsGrad / the next forward
         self.next_conf = None                 # set by utils.checkpoint.set_hierarchical_config: the stage switch takes effect at the
         self.next_train_conf = None           # next scheduled remesh (update_hierarchical_config, network.py:172-205,464)
 
