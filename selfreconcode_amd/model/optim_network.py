@@ -643,19 +643,19 @@ class OptimNetwork(nn.Module):
                 # (the rays of the converged pixels from the branch's own camera object: the same rows as rays[conv_idx], bit for bit)
                 self.rays = r_cameras.view_rays(pixels[conv_idx]) if (eager and cam_learn) else rays[conv_idx]
                 extra = self.loss_color_normal(datas, gtCs, r_cameras, [r_dcond, [r_poses, r_trans]], r_rendcond, ratio, N)
+                if on_rb_side and torch.is_tensor(extra):
+                    known = torch.cuda.Event()           # the VALUE of the two terms joins the returned loss on the main stream; the forward
+                    known.record(rb)                     # of the branch is queued long before the main stream gets to that addition
+                    main.wait_event(known)
+                    extra.detach().record_stream(main)
                 if eager and torch.is_tensor(extra) and extra.requires_grad:
-                    value = extra.detach()
-                    known = torch.cuda.Event()
-                    known.record(rb)
                     self._mark('ray branch forward issued')
+                    value = extra.detach()
                     extra.backward()                     # inner backward: TmpPs.grad, the stand-ins' gradients, the deferred weight gradients
                     ctx['bwd_done'] = torch.cuda.Event()
                     ctx['bwd_done'].record(rb)
                     self._mark('ray branch backward done (its stream)')
                     self._ray_ctx = ctx
-                    if on_rb_side:
-                        main.wait_event(known)           # (the VALUE of the two terms joins the returned loss; the forward of the branch is
-                        value.record_stream(main)        #  queued long before the main stream gets here)
                     extra = value
             total_loss = total_loss + extra
 
