@@ -392,7 +392,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     from selfreconcode_amd import dist as srdist
-    rank, world, device = srdist.init_from_env("cuda")
+    rank, world, device = srdist.init_from_env("cuda", bind_cpus=True)     # (host threads on a core group of the GPU's NUMA node; SR_BIND_CPUS=0: off)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
     rccl = srdist.describe()                                  # (a collective: every rank calls it)
@@ -516,7 +516,7 @@ def main():
         "remesh": main_rec["remesh"], "ms_per_step_remesh_amortised": main_rec["ms_per_step_remesh_amortised"],
         "ms_per_step_instrumented": main_rec["ms_per_step_instrumented"],
         "refiner_ms_per_step": main_rec["refiner_ms_per_step"],
-        "diagnostics": dict(main_rec["diagnostics"], note="taken inside the headline window: shader clock / socket power from sysfs half-way through and after the last step was "
+        "diagnostics": dict(main_rec["diagnostics"], host_threads=srdist.PLACEMENT, note="host_threads = the CPUs rank 0's threads are confined to (selfreconcode_amd/affinity.py); the rest is taken inside the headline window: shader clock / socket power from sysfs half-way through and after the last step was "
                                                           "issued; host_issue_ms_per_step = host time to enqueue a step, host_ahead_ms_at_the_end = how long the final synchronisation waited "
                                                           "(~0 means the host paces the step)"),
         "regime_lr_config": main_rec.get("regime_lr_config"),
@@ -558,6 +558,8 @@ def main():
         with open(args.shape_log, "w") as fh:
             json.dump(shapes, fh, indent=1)
     if world == 1 and not args.no_cpu_baseline and not args.simulate_world:
+        from selfreconcode_amd import affinity
+        affinity.restore()                                    # the CPU leg gets the machine the process was started with
         out["cpu_baseline"] = cpu_baseline_record(args, device)
     print(json.dumps(out), flush=True)
 

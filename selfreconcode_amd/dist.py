@@ -8,16 +8,27 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(device_type="cuda"):
-    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns (rank, world, device)."""
+PLACEMENT = None       # what affinity.bind did for this rank (init_from_env(bind_cpus=True)); bench.py prints it
+
+
+def init_from_env(device_type="cuda", bind_cpus=False):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns (rank, world, device).
+    `bind_cpus`: confine the rank's host threads to a group of cores of its GPU's NUMA node, one group per local rank
+    (selfreconcode_amd/affinity.py: the step is ~2 600 launches issued by threads that hand over to each other; at one frame per rank the
+    host paces it)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if device_type == "cuda":
+        slot = local
         if os.environ.get("SR_ALL_RANKS_ON_DEVICE0") == "1":      # functional test of the N>1 path on a 1-GPU box
             local = 0
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
+        if bind_cpus:
+            from . import affinity
+            global PLACEMENT
+            PLACEMENT = affinity.bind(local, slot=slot)
     else:
         device = torch.device("cpu")
     global _FORCED

@@ -1,7 +1,8 @@
 """Host round trips of the iteration (bool mask -> index list).
 
 `mask.nonzero()` is a count kernel, a small device-to-host copy and a blocking wait of the calling thread for that copy.  This module
-is the one place the iteration's six round trips go through, so that they can be traced (TRACE: tools/host_profile.py stamps the
+is the one place the iteration's round trips go through (two per iteration with the fused selection, six without:
+`nonzero_many` carries several counts in one), so that they can be traced (TRACE: tools/host_profile.py stamps the
 device clock when the count copy is issued and the host clock when the count arrives) and so that the wait can be switched to a
 polling one (SR_HOST_POLL=1: asynchronous copy to pinned memory, hipEventQuery in a loop, then torch.nonzero_static with the size
 known).  Measured on MI355X / ROCm 7.2: both forms return within ~20 us of the count being ready on the GPU; what looked like a
@@ -45,3 +46,29 @@ def nonzero(mask, as_tuple=False):
     n = count_to_host(mask.count_nonzero())
     idx = torch.nonzero_static(mask, size=n)
     return idx.unbind(1) if as_tuple else idx
+
+
+def nonzero_many(masks):
+    """Index lists (1-D int64) of several 1-D bool CUDA masks with ONE host round trip: the counts travel together, the lists are then
+    made with their sizes known (torch.nonzero_static: no synchronisation).  Same rows, same order as mask.nonzero().view(-1)."""
+    counts = torch.stack([m.count_nonzero() for m in masks])
+    if POLL and counts.is_cuda:
+        key = (counts.device.index, torch.cuda.current_stream(counts.device).cuda_stream, len(masks))
+        buf = _pinned.get(key)
+        if buf is None:
+            buf = _pinned[key] = torch.zeros(len(masks), dtype=torch.int64).pin_memory()
+        buf.copy_(counts, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        if TRACE is not None:
+            TRACE('count copy issued')
+        while not ev.query():
+            pass
+        n = buf.tolist()
+    else:
+        if TRACE is not None:
+            TRACE('count copy issued')
+        n = counts.tolist()
+    if TRACE is not None:
+        TRACE('count on the host')
+    return [torch.nonzero_static(m, size=int(k)).view(-1) for m, k in zip(masks, n)]

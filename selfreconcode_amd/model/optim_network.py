@@ -49,6 +49,15 @@ EAGER_RAY_BRANCH = os.environ.get('SR_EAGER_RAY_BRANCH', '1') != '0'
 # join: the refiner used to end ~2.5 ms after the main stream had drained, with nothing but its last few-hundred-row phases on the
 # machine.  Same gradient, same sum; the returned loss carries the term's value.
 EAGER_TEMPLATE_TERM = os.environ.get('SR_EAGER_TEMPLATE_TERM', '1') != '0'
+# Ray selection and the two vertex subsets with ONE host round trip instead of five.  The reference filters the rasterised pixels three
+# times (inside a face, inside the ground-truth mask, a Bernoulli subsample whose probability depends on the count so far:
+# network.py:519-526) and draws two Bernoulli vertex subsets (utils.py:74-84 via network.py:543,565), each filter a boolean-mask
+# index = a count, a device-to-host copy and a wait.  Here the three ray filters are evaluated on the device in one pass -- the rank
+# of a pixel in the twice-filtered list is a prefix sum, the count that sets the subsampling probability stays in device memory -- and
+# the three counts (rays, eikonal vertices, regulariser vertices) come back in one copy.  Same rays, same order, same seeds, bit for
+# bit (tests/test_selection_gpu.py); with fresh random numbers the draw is over all pixels instead of over the count, i.e. another
+# stream of the same distribution.  Off = the sequential form.
+FUSED_SELECTION = os.environ.get('SR_FUSED_SELECTION', '1') != '0'
 _SIDE_STREAMS = {}
 
 
@@ -400,7 +409,7 @@ class OptimNetwork(nn.Module):
         self.info['pc_loss'] = {}
 
         # Two streams.  The template branch (silhouette, mask loss, its backward, the template SGD step, |f(TmpVs)|) is a few
-        # large kernels; the ray selection is a handful of tiny kernels and five host syncs (nonzero), and the refiner after it
+        # large kernels; the ray selection is a handful of tiny kernels and one host sync (five in its sequential form), and the refiner after it
         # is thousands of small launches whose cost is host-side issue time.  So: the template branch is queued FIRST on the
         # main stream; the selection runs on a side stream that only waits for the deformed template, so its syncs return
         # while the GPU is still busy with the template branch; the (sync-free) refiner is then issued behind it.
@@ -420,35 +429,81 @@ class OptimNetwork(nn.Module):
         total_loss = self.computeTmpPcLoss(defTmpVs, defconds, masks, mgtMs, ratio)
         self._mark('template branch issued')
 
+        use_regu = 'def_regu' in self.conf and self.conf.get_float('def_regu.weight') > 0.
+        sample_pix = self.conf.get_int('sample_pix_num') if 'sample_pix_num' in self.conf else sample_pix
+        fused_sel = FUSED_SELECTION and 'frags' not in datas and self.seed_mode == "mesh"
+        eik_idx = regu_idx = None
         with torch.cuda.stream(side):
             side.wait_event(fork)
             self._debug_delay('side_after_wait')
-            with torch.no_grad():
-                if 'frags' in datas:
-                    batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(seedVs, self.Tmpfs, datas['frags'])
-                elif self.seed_mode == "mesh":            # in-repo hard mesh rasteriser -> FindSurfacePs, as the reference does with pytorch3d
+            if fused_sel:
+                with torch.no_grad():
                     self._mark('sel: entered')
                     xy, z = cameras.project_ndc(defTmpVs.detach())
                     self._mark('sel: projected')
                     frags = rasterize_meshes(xy, z, self.Tmpfs, H, W)
                     self._mark('sel: rasterised')
                     if debug is not None:
-                        debug.update(proj_xy=xy.clone(), proj_z=z.clone(), pix_to_face=(frags[0] if isinstance(frags, (tuple, list)) else frags.pix_to_face).clone())
-                    batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(seedVs, self.Tmpfs, frags)
-                    self._mark('sel: seeds found')
-                else:
-                    batch_inds, row_inds, col_inds, initTmpPs = self._seed_rays(defTmpVs.detach(), cameras, H, W, seedVs)
-            # boolean masks are turned into index lists ONCE (each `x[mask]` is its own nonzero + host sync)
-            sel = hostsync.nonzero(gtMs[batch_inds, row_inds, col_inds] > 0.).view(-1)
-            batch_inds, row_inds, col_inds, initTmpPs = batch_inds[sel], row_inds[sel], col_inds[sel], initTmpPs[sel]
-            self._mark('sel: inside the mask')
-            pnum = batch_inds.shape[0]
-            sample_pix = self.conf.get_int('sample_pix_num') if 'sample_pix_num' in self.conf else sample_pix
-            if pnum > sample_pix * N:
-                u = rand['ray_select'][:pnum] if 'ray_select' in rand else torch.rand(pnum, device=device)
-                sel = hostsync.nonzero(u < float(sample_pix * N) / float(pnum)).view(-1)
+                        debug.update(proj_xy=xy.clone(), proj_z=z.clone(), pix_to_face=frags.pix_to_face.clone())
+                    # FindSurfacePs' pixel test (first fragment inside its face) AND the ground-truth mask, as one image-shaped flag
+                    K = frags.pix_to_face.shape[-1]
+                    inner = (frags.bary_coords > 0.0).all(-1) & (frags.pix_to_face >= 0)
+                    ks = torch.arange(K, device=device).view(1, 1, 1, K).expand_as(inner)
+                    first = torch.where(inner, ks, torch.full_like(ks, K)).amin(dim=-1)
+                    flag = ((first < K) & (gtMs > 0.)).view(-1)
+                    # the Bernoulli subsample: pixel i of the filtered list keeps its place when u[i] < sample / count -- i is the
+                    # exclusive prefix sum of the flags, the count its last element; the reference's float(sample) / float(count)
+                    # is a double division rounded to float32 by the comparison, and so is this
+                    rank = torch.cumsum(flag, 0) - 1
+                    pnum_dev = rank[-1] + 1
+                    u = rand['ray_select'] if 'ray_select' in rand else torch.rand(flag.numel(), device=device)
+                    cap = float(sample_pix * N)
+                    thr = torch.where(pnum_dev > sample_pix * N, (cap / pnum_dev.double()).float(), torch.full((), 2., device=device))
+                    keep = flag & (u[rank.clamp(min=0, max=u.numel() - 1)] < thr)
+                    masks_1d = [keep]
+                    vsel = rand['vert_select'][:TmpVnum] if 'vert_select' in rand else torch.rand(TmpVnum, device=device)
+                    masks_1d.append(vsel < 4096. / float(TmpVnum))
+                    if use_regu:
+                        vsel2 = rand['vert_select2'][:TmpVnum] if 'vert_select2' in rand else torch.rand(TmpVnum, device=device)
+                        masks_1d.append(vsel2 < 4096. / float(TmpVnum))
+                    lists = hostsync.nonzero_many(masks_1d)                  # THE round trip of the selection
+                    self._debug_delay('side_lists_made')
+                    self._mark('sel: inside the mask')
+                    lin = lists[0]
+                    batch_inds, row_inds, col_inds = lin // (H * W), (lin // W) % H, lin % W
+                    eik_idx = lists[1]
+                    regu_idx = lists[2] if use_regu else None
+                    kk = first.view(-1)[lin].clamp(max=K - 1).view(-1, 1)
+                    finds = torch.gather(frags.pix_to_face.view(-1, K)[lin], 1, kk).view(-1) % self.Tmpfs.shape[0]
+                    ws = torch.gather(frags.bary_coords.view(-1, K, 3)[lin], 1, kk.view(-1, 1, 1).expand(-1, 1, 3)).view(-1, 3)
+                    initTmpPs = (seedVs[self.Tmpfs[finds].view(-1)].view(-1, 3, 3) * ws[:, :, None]).sum(1)
+                    pnum = batch_inds.shape[0]
+            else:
+                with torch.no_grad():
+                    if 'frags' in datas:
+                        batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(seedVs, self.Tmpfs, datas['frags'])
+                    elif self.seed_mode == "mesh":            # in-repo hard mesh rasteriser -> FindSurfacePs, as the reference does with pytorch3d
+                        self._mark('sel: entered')
+                        xy, z = cameras.project_ndc(defTmpVs.detach())
+                        self._mark('sel: projected')
+                        frags = rasterize_meshes(xy, z, self.Tmpfs, H, W)
+                        self._mark('sel: rasterised')
+                        if debug is not None:
+                            debug.update(proj_xy=xy.clone(), proj_z=z.clone(), pix_to_face=(frags[0] if isinstance(frags, (tuple, list)) else frags.pix_to_face).clone())
+                        batch_inds, row_inds, col_inds, initTmpPs, _ = FindSurfacePs(seedVs, self.Tmpfs, frags)
+                        self._mark('sel: seeds found')
+                    else:
+                        batch_inds, row_inds, col_inds, initTmpPs = self._seed_rays(defTmpVs.detach(), cameras, H, W, seedVs)
+                # boolean masks are turned into index lists ONCE (each `x[mask]` is its own nonzero + host sync)
+                sel = hostsync.nonzero(gtMs[batch_inds, row_inds, col_inds] > 0.).view(-1)
                 batch_inds, row_inds, col_inds, initTmpPs = batch_inds[sel], row_inds[sel], col_inds[sel], initTmpPs[sel]
+                self._mark('sel: inside the mask')
                 pnum = batch_inds.shape[0]
+                if pnum > sample_pix * N:
+                    u = rand['ray_select'][:pnum] if 'ray_select' in rand else torch.rand(pnum, device=device)
+                    sel = hostsync.nonzero(u < float(sample_pix * N) / float(pnum)).view(-1)
+                    batch_inds, row_inds, col_inds, initTmpPs = batch_inds[sel], row_inds[sel], col_inds[sel], initTmpPs[sel]
+                    pnum = batch_inds.shape[0]
             pixels = torch.stack([col_inds, row_inds, torch.ones_like(col_inds)], dim=-1).float()
             rays = cameras.view_rays(pixels)
             initTmpPs = initTmpPs.contiguous()
@@ -488,21 +543,23 @@ class OptimNetwork(nn.Module):
             refined.record(rstream)
             self._mark('refiner done (its stream)')
         self._mark('refiner issued')
-        aux = self._side_stream(device, 1)
-        with torch.cuda.stream(aux), torch.no_grad():
-            # vertex subsets of the eikonal / def-regu samples: the Bernoulli masks do not depend on the vertex positions, so their
-            # index lists (one host sync each) are made on a stream of their own AFTER the refiner has been issued -- nothing
-            # before the refiner waits for them, and they do not wait for the refiner; the gathers happen after the template step,
-            # as in the reference
-            aux.wait_event(fork)
-            self._debug_delay('aux_after_wait')
-            vsel = rand['vert_select'][:TmpVnum] if 'vert_select' in rand else torch.rand(TmpVnum, device=device)
-            eik_idx = hostsync.nonzero(vsel < 4096. / float(TmpVnum)).view(-1)
-            use_regu = 'def_regu' in self.conf and self.conf.get_float('def_regu.weight') > 0.
-            regu_idx = None
-            if use_regu:
-                vsel2 = rand['vert_select2'][:TmpVnum] if 'vert_select2' in rand else torch.rand(TmpVnum, device=device)
-                regu_idx = hostsync.nonzero(vsel2 < 4096. / float(TmpVnum)).view(-1)
+        if eik_idx is None:
+            aux = self._side_stream(device, 1)
+            with torch.cuda.stream(aux), torch.no_grad():
+                # (sequential selection) vertex subsets of the eikonal / def-regu samples: the Bernoulli masks do not depend on the vertex
+                # positions, so their index lists (one host sync each) are made on a stream of their own AFTER the refiner has been issued
+                # -- nothing before the refiner waits for them, and they do not wait for the refiner; the gathers happen after the
+                # template step, as in the reference
+                aux.wait_event(fork)
+                self._debug_delay('aux_after_wait')
+                vsel = rand['vert_select'][:TmpVnum] if 'vert_select' in rand else torch.rand(TmpVnum, device=device)
+                eik_idx = hostsync.nonzero(vsel < 4096. / float(TmpVnum)).view(-1)
+                if use_regu:
+                    vsel2 = rand['vert_select2'][:TmpVnum] if 'vert_select2' in rand else torch.rand(TmpVnum, device=device)
+                    regu_idx = hostsync.nonzero(vsel2 < 4096. / float(TmpVnum)).view(-1)
+            join_vertex_lists = lambda: main.wait_stream(aux)
+        else:
+            join_vertex_lists = lambda: main.wait_event(selected)       # (made with the ray selection, on its stream)
         # The eikonal and deformation-regulariser samples are [refined ray points ; a random subset of the template vertices] (+ uniform
         # samples): the vertex / uniform part does not depend on the refiner, which -- 200 dependent launches of a few thousand rows each,
         # under the template branch's large kernels -- finishes ~2.5 ms AFTER the main stream has drained the template branch
@@ -510,7 +567,7 @@ class OptimNetwork(nn.Module):
         # stream waits for the refiner, the ray one after it; the means are recombined with their counts (SPLIT_SAMPLE_TERMS = False:
         # one batch each, as the reference writes it).
         self._debug_delay('main_before_join')
-        main.wait_stream(aux)
+        join_vertex_lists()
         for t in (eik_idx, regu_idx):
             if t is not None:
                 t.record_stream(main)

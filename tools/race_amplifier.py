@@ -31,7 +31,8 @@ torch.save(outs, sys.argv[1])
 ''' % (ROOT, ROOT)
 import torch
 configs = [("baseline", {}), ("main held 6 ms after the fork", {"SR_DEBUG_DELAY": "main_after_fork:6"}), ("side held 8 ms after its wait", {"SR_DEBUG_DELAY": "side_after_wait:8"}),
-           ("refiner held 10 ms", {"SR_DEBUG_DELAY": "refiner_start:10"}), ("aux held 10 ms", {"SR_DEBUG_DELAY": "aux_after_wait:10"}),
+           ("refiner held 10 ms", {"SR_DEBUG_DELAY": "refiner_start:10"}), ("selection stream held 10 ms after the index lists' round trip", {"SR_DEBUG_DELAY": "side_lists_made:10"}),
+           ("sequential selection, vertex-subset stream held 10 ms", {"SR_DEBUG_DELAY": "aux_after_wait:10", "SR_FUSED_SELECTION": "0"}),
            ("main held 10 ms before it joins the side streams", {"SR_DEBUG_DELAY": "main_before_join:10"}),
            ("ray branch held 12 ms at its start (the main stream runs the sampled terms and the big backward meanwhile)", {"SR_DEBUG_DELAY": "ray_branch_start:12"}),
            ("implicit-gradient pass held 12 ms on the ray branch's stream", {"SR_DEBUG_DELAY": "ray_branch_propagate_start:12"}),
