@@ -9,10 +9,12 @@ to one NUMA node 19.3-21.9; to 8 cores + their SMT siblings 18.5 with taskset, 1
 (8 cores of the OTHER socket: 19.5).  At three frames per rank the GPU paces the step and placement does not show.
 
 `bind()` confines the calling process -- every thread it has and every thread it creates later -- to `cores` physical cores (and their
-SMT siblings) of the NUMA node its GPU hangs on; ranks that share a node take consecutive groups (`slot` = the local rank), so 8 ranks
-on a 2 x 64-core box get 8 disjoint groups of 8.  `restore()` undoes it (bench.py: before the CPU-baseline leg, which wants the whole
-machine).  Only ever narrows the set the process was started with (taskset / cgroup limits are respected); does nothing where sysfs
-does not describe the machine.  SR_BIND_CPUS=0 switches it off, SR_BIND_CORES=<n> sets the group size (default 8)."""
+SMT siblings) of the NUMA node its GPU hangs on.  Ranks that share a node take different groups, so 8 ranks on a 2 x 64-core box get 8
+disjoint groups of 8: by default the group number is the position of the GPU among the GPUs of its node in PCI order, which every
+process on the box computes alike -- single-GPU jobs of different tenants do not pile onto one group either.  `restore()` undoes it
+(bench.py: before the CPU-baseline leg, which wants the whole machine).  Only ever narrows the set the process was started with
+(taskset / cgroup limits are respected); does nothing where sysfs does not describe the machine.  SR_BIND_CPUS=0 switches it off,
+SR_BIND_CORES=<n> sets the group size (default 8)."""
 import os
 
 _ORIGINAL = None
@@ -53,6 +55,43 @@ def gpu_numa_node(device_index):
     except (AttributeError, ValueError, RuntimeError, AssertionError):
         return None
     return node if node >= 0 else None
+
+
+def gpus_by_node(drm_root="/sys/class/drm"):
+    """{numa node: sorted PCI addresses of the GPUs on it} from the DRM cards sysfs lists -- ALL of the box's, whatever this process
+    may see of them."""
+    out = {}
+    try:
+        cards = os.listdir(drm_root)
+    except OSError:
+        return out
+    for c in cards:
+        if not c.startswith("card") or "-" in c:
+            continue
+        addr = os.path.basename(os.path.realpath(os.path.join(drm_root, c, "device")))
+        if addr.count(":") != 2:                                   # (amdgpu_xcp_* partitions are not PCI functions)
+            continue
+        text = _read("/sys/bus/pci/devices/%s/numa_node" % addr)
+        try:
+            node = int(text)
+        except (TypeError, ValueError):
+            continue
+        if node >= 0 and addr not in out.setdefault(node, []):
+            out[node].append(addr)
+    return {n: sorted(a) for n, a in out.items()}
+
+
+def gpu_slot(device_index):
+    """Position of this GPU among the GPUs of its NUMA node (PCI address order): the same answer in every process and every container
+    on the box, so that neither the ranks of one job nor single-GPU jobs of different tenants pick the same core group."""
+    try:
+        addr = gpu_pci_address(device_index)
+    except (AttributeError, RuntimeError, AssertionError):
+        return None
+    for node, addrs in gpus_by_node().items():
+        if addr in addrs:
+            return addrs.index(addr)
+    return None
 
 
 def node_cpus(node):
@@ -102,8 +141,10 @@ def _set_all_threads(cpus):
     os.sched_setaffinity(0, cpus)                 # the caller: what new threads inherit
 
 
-def bind(device_index=None, slot=0, cores=None):
-    """Confine this process as described above.  Returns a record of what was done (bench.py prints it) or of why nothing was."""
+def bind(device_index=None, slot=None, cores=None, fallback_slot=0):
+    """Confine this process as described above.  `slot` = which core group of the node; None: the position of the GPU among the GPUs of
+    its node (`gpu_slot`), `fallback_slot` (the local rank) where sysfs cannot tell.  Returns a record of what was done (bench.py prints
+    it) or of why nothing was."""
     global _ORIGINAL
     if os.environ.get("SR_BIND_CPUS", "1") == "0":
         return {"bound": False, "why": "SR_BIND_CPUS=0"}
@@ -112,6 +153,12 @@ def bind(device_index=None, slot=0, cores=None):
     cores = int(os.environ.get("SR_BIND_CORES", "8")) if cores is None else int(cores)
     allowed = sorted(os.sched_getaffinity(0)) if _ORIGINAL is None else sorted(_ORIGINAL)
     node = gpu_numa_node(device_index) if device_index is not None else None
+    slot_from = "given"
+    if slot is None:
+        slot = gpu_slot(device_index) if device_index is not None else None
+        slot_from = "position of the GPU on its NUMA node"
+        if slot is None:
+            slot, slot_from = fallback_slot, "local rank"
     preferred = node_cpus(node) if node is not None else None
     chosen = plan(allowed, preferred, siblings_of, slot, cores)
     if not chosen:
@@ -120,7 +167,7 @@ def bind(device_index=None, slot=0, cores=None):
         _ORIGINAL = set(allowed)
     _set_all_threads(chosen)
     return {"bound": True, "cpus": _compact(chosen), "logical_cpus": len(chosen), "physical_cores": cores, "numa_node": node, "slot": slot,
-            "of_allowed": len(allowed)}
+            "slot_from": slot_from, "of_allowed": len(allowed)}
 
 
 def restore():

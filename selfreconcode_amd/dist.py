@@ -28,7 +28,7 @@ def init_from_env(device_type="cuda", bind_cpus=False):
         if bind_cpus:
             from . import affinity
             global PLACEMENT
-            PLACEMENT = affinity.bind(local, slot=slot)
+            PLACEMENT = affinity.bind(local, fallback_slot=slot)
     else:
         device = torch.device("cpu")
     global _FORCED

@@ -77,3 +77,28 @@ def test_bind_moves_every_thread_and_restore_undoes_it():
     assert after == [tuple(before)]
     off = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=dict(env, SR_BIND_CPUS="0"), timeout=120)
     assert eval(off.stdout.strip().splitlines()[-1])[1] == {"bound": False, "why": "SR_BIND_CPUS=0"}
+
+
+def test_gpu_position_on_its_node_from_a_sysfs_tree(tmp_path, monkeypatch):
+    """The listing of a pool box: eight GPUs (PCI functions) among 64 DRM cards, the rest compute partitions without a PCI address."""
+    pci = {"0000:0a:00.0": 0, "0000:2e:00.0": 0, "0000:54:00.0": 0, "0000:72:00.0": 0, "0000:8b:00.0": 1, "0000:a4:00.0": 1, "0000:bd:00.0": 1, "0000:d9:00.0": 1}
+    drm = tmp_path / "drm"; drm.mkdir()
+    devs = tmp_path / "devices"; devs.mkdir()
+    for i, addr in enumerate(sorted(pci, reverse=True)):                  # card numbers do not follow the PCI order
+        (devs / addr).mkdir()
+        (drm / f"card{8 * i}").mkdir()
+        os.symlink(devs / addr, drm / f"card{8 * i}" / "device")
+        (drm / f"card{8 * i}-DP-1").mkdir()                               # connector entries are skipped
+        for j in range(1, 8):
+            x = tmp_path / f"amdgpu_xcp_{7 * i + j}"; x.mkdir()
+            (drm / f"card{8 * i + j}").mkdir()
+            os.symlink(x, drm / f"card{8 * i + j}" / "device")
+    monkeypatch.setattr(A, "_read", lambda path: str(pci[os.path.basename(os.path.dirname(path))]) if path.endswith("numa_node") else None)
+    by_node = A.gpus_by_node(str(drm))
+    assert by_node == {0: sorted(a for a in pci if pci[a] == 0), 1: sorted(a for a in pci if pci[a] == 1)}
+    monkeypatch.setattr(A, "gpus_by_node", lambda: by_node)
+    for addr, want in (("0000:0a:00.0", 0), ("0000:72:00.0", 3), ("0000:8b:00.0", 0), ("0000:d9:00.0", 3)):
+        monkeypatch.setattr(A, "gpu_pci_address", lambda i, a=addr: a)
+        assert A.gpu_slot(0) == want
+    monkeypatch.setattr(A, "gpu_pci_address", lambda i: "0000:ff:00.0")
+    assert A.gpu_slot(0) is None                                           # unknown device: the caller falls back to the local rank

@@ -16,7 +16,7 @@ if int(os.environ.get('SR_HP_SIM_WORLD', '0')) > 1:
 dev = torch.device('cuda:0')
 if os.environ.get('SR_HP_BIND', '0') != '0':                  # the placement bench.py uses (selfreconcode_amd/affinity.py); SR_HP_SLOT = which core group
     from selfreconcode_amd import affinity
-    print('host threads:', affinity.bind(0, slot=int(os.environ.get('SR_HP_SLOT', '0'))))
+    print('host threads:', affinity.bind(0, slot=int(os.environ['SR_HP_SLOT']) if 'SR_HP_SLOT' in os.environ else None))
 net, ds, conf = build_synthetic_scene(device=dev, frame_num=64, stage=os.environ.get('SR_HP_STAGE', 'coarse'), consistent_masks=False)
 params = [p for p in net.parameters() if p.requires_grad]
 mlp_engine.set_deferred_param_grads(True)
