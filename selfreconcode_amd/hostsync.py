@@ -48,15 +48,16 @@ def nonzero(mask, as_tuple=False):
     return idx.unbind(1) if as_tuple else idx
 
 
-def nonzero_many(masks):
+def nonzero_many(masks, also=()):
     """Index lists (1-D int64) of several 1-D bool CUDA masks with ONE host round trip: the counts travel together, the lists are then
-    made with their sizes known (torch.nonzero_static: no synchronisation).  Same rows, same order as mask.nonzero().view(-1)."""
-    counts = torch.stack([m.count_nonzero() for m in masks])
+    made with their sizes known (torch.nonzero_static: no synchronisation).  Same rows, same order as mask.nonzero().view(-1).
+    `also`: 0-dim integer device tensors that ride along; with them the result is (lists, their values as ints)."""
+    counts = torch.stack([m.count_nonzero() for m in masks] + [a.to(torch.int64).view(()) for a in also])
     if POLL and counts.is_cuda:
-        key = (counts.device.index, torch.cuda.current_stream(counts.device).cuda_stream, len(masks))
+        key = (counts.device.index, torch.cuda.current_stream(counts.device).cuda_stream, int(counts.numel()))
         buf = _pinned.get(key)
         if buf is None:
-            buf = _pinned[key] = torch.zeros(len(masks), dtype=torch.int64).pin_memory()
+            buf = _pinned[key] = torch.zeros(int(counts.numel()), dtype=torch.int64).pin_memory()
         buf.copy_(counts, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -71,4 +72,5 @@ def nonzero_many(masks):
         n = counts.tolist()
     if TRACE is not None:
         TRACE('count on the host')
-    return [torch.nonzero_static(m, size=int(k)).view(-1) for m, k in zip(masks, n)]
+    lists = [torch.nonzero_static(m, size=int(k)).view(-1) for m, k in zip(masks, n)]
+    return (lists, [int(k) for k in n[len(masks):]]) if also else lists

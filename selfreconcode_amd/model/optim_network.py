@@ -466,7 +466,9 @@ class OptimNetwork(nn.Module):
                     if use_regu:
                         vsel2 = rand['vert_select2'][:TmpVnum] if 'vert_select2' in rand else torch.rand(TmpVnum, device=device)
                         masks_1d.append(vsel2 < 4096. / float(TmpVnum))
-                    lists = hostsync.nonzero_many(masks_1d)                  # THE round trip of the selection
+                    lists, (pnum_all,) = hostsync.nonzero_many(masks_1d, also=[pnum_dev])        # THE round trip of the selection
+                    if pnum_all > u.numel():
+                        raise ValueError(f"rand['ray_select'] holds {u.numel()} numbers, {pnum_all} pixels passed the two mask filters")
                     self._debug_delay('side_lists_made')
                     self._mark('sel: inside the mask')
                     lin = lists[0]
