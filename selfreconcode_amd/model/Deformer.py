@@ -70,7 +70,7 @@ class MLPTranslator(nn.Module):
         from ..mlp_engine import packed_weights_of
         return packed_weights_of(self, len(self.spec.layers))
 
-    def hoisted_first_layer(self, conds):
+    def hoisted_first_layer(self, conds, frames=None):
         """The per-frame code enters the first layer only through W0[:, PE:] code_f -- a constant per frame.  For batches laid out
         frame by frame ([N, V, 3]) that product is taken out of the per-point GEMM: the layer becomes [512 x 39] on PE(p) with a
         per-frame bias B_f = W0[:, 39:] code_f + b0 (-15 % of the deformer's FLOPs, K = 167 -> 39 in the first-layer
@@ -78,6 +78,10 @@ class MLPTranslator(nn.Module):
         npe = 3 + 6 * self.multires
         W0 = self.lin0.weight
         Bf = conds.reshape(-1, self.feature_vector_size) @ W0[:, npe:].t() + self.lin0.bias            # [N, 512]
+        if frames is not None and Bf.shape[0] != frames:
+            # (one bias row per row segment is what mlp_engine._bias_segments assumes; a code tensor with another number of rows would
+            # still divide the batch -- and silently pair points with the wrong frame's code.  The reference's cat of the points with the expanded codes, Deformer.py:61, raises here too.)
+            raise ValueError(f"MLPTranslator: {Bf.shape[0]} condition codes for a batch of {frames} frames")
         W0p = pad_cols(W0[:, :npe], pad4(npe))                                                          # [512, pad4(39)] (a copy: never a deferred sink)
         spec = getattr(self, "_spec_pe", None)
         if spec is None:
@@ -88,7 +92,7 @@ class MLPTranslator(nn.Module):
         ratio = kwargs['ratio']['deformerRatio']
         ws = resolve_band_weights(self.multires, ratio)
         if batch_inds is None and HOIST_FRAME_CODE and ps.dim() == 3:
-            spec, W0p, Bf = self.hoisted_first_layer(conds)
+            spec, W0p, Bf = self.hoisted_first_layer(conds, ps.shape[0])
             Ws, bs = self.packed_weights()
             if BATCH_FRAMES:
                 # all frames in ONE batch: the first layer runs per frame (its bias is the frame's), every other layer once over
@@ -562,7 +566,7 @@ def translator_value_jacobian(tr, ps, conds, batch_inds, ratio):
         seg = ps.shape[1]
     Ws, bs = tr.packed_weights()
     if batch_inds is None and HOIST_FRAME_CODE and ps.dim() == 3:            # frame-major batch: code product as a per-frame bias
-        spec, W0p, Bf = tr.hoisted_first_layer(conds)
+        spec, W0p, Bf = tr.hoisted_first_layer(conds, ps.shape[0])
         if BATCH_FRAMES:                                                       # one group-4 batch over all frames (see MLPTranslator.forward)
             return TranslatorValueJacobian.apply(tr, r, ps.contiguous(), None, None, 0, spec, W0p, *Ws[1:], Bf, *bs[1:])
         ds_, Js_ = [], []

@@ -140,3 +140,17 @@ def test_segmented_first_layer_bias_is_validated():
         me._bias_segments(torch.zeros(5, 8), 12, 1)       # rows not divisible by the segments
     with pytest.raises(RuntimeError):
         me._bias_segments(torch.zeros(3, 8), 18, 4)       # a segment that would split a (primal, tangents) group
+
+
+def test_hoisted_first_layer_wants_one_code_per_frame():
+    """The frame-major deformer batch pairs row segment s with bias row s (mlp_engine._bias_segments): a code tensor with another
+    number of rows than the batch has frames must not be accepted (the reference's cat of points and expanded codes, Deformer.py:58-61, raises for it)."""
+    import pytest
+    from selfreconcode_amd.model.Deformer import MLPTranslator
+    tr = MLPTranslator(128, 6)
+    spec, W0p, Bf = tr.hoisted_first_layer(torch.zeros(3, 128), 3)
+    assert W0p.shape == (512, 40) and Bf.shape == (3, 512) and spec.K0 == 39
+    with pytest.raises(ValueError):
+        tr.hoisted_first_layer(torch.zeros(1, 128), 3)
+    with pytest.raises(ValueError):
+        tr.hoisted_first_layer(torch.zeros(6, 128), 3)
