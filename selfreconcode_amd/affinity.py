@@ -142,6 +142,19 @@ def _set_all_threads(cpus):
 
 
 def bind(device_index=None, slot=None, cores=None, fallback_slot=0):
+    """`_bind`, but placement is an optimisation: whatever goes wrong (a sysfs layout this module has not seen, a sandbox that refuses
+    sched_setaffinity) is reported in the record and the process runs where it was."""
+    try:
+        return _bind(device_index, slot, cores, fallback_slot)
+    except Exception as e:          # noqa: BLE001 -- deliberately broad, see above
+        try:
+            restore()
+        except Exception:           # noqa: BLE001
+            pass
+        return {"bound": False, "why": "%s: %s" % (type(e).__name__, e)}
+
+
+def _bind(device_index=None, slot=None, cores=None, fallback_slot=0):
     """Confine this process as described above.  `slot` = which core group of the node; None: the position of the GPU among the GPUs of
     its node (`gpu_slot`), `fallback_slot` (the local rank) where sysfs cannot tell.  Returns a record of what was done (bench.py prints
     it) or of why nothing was."""
@@ -173,9 +186,9 @@ def bind(device_index=None, slot=None, cores=None, fallback_slot=0):
 def restore():
     """Back to the set the process was started with."""
     global _ORIGINAL
-    if _ORIGINAL is not None:
-        _set_all_threads(_ORIGINAL)
-        _ORIGINAL = None
+    original, _ORIGINAL = _ORIGINAL, None
+    if original is not None:
+        _set_all_threads(original)
 
 
 def _compact(cpus):

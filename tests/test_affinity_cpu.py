@@ -102,3 +102,13 @@ def test_gpu_position_on_its_node_from_a_sysfs_tree(tmp_path, monkeypatch):
         assert A.gpu_slot(0) == want
     monkeypatch.setattr(A, "gpu_pci_address", lambda i: "0000:ff:00.0")
     assert A.gpu_slot(0) is None                                           # unknown device: the caller falls back to the local rank
+
+
+def test_a_refused_placement_is_reported_not_raised(monkeypatch):
+    def refuse(*a):
+        raise PermissionError("sandbox")
+    monkeypatch.setattr(A, "_set_all_threads", refuse)
+    monkeypatch.delenv("SR_BIND_CPUS", raising=False)
+    rec = A.bind(None, slot=0, cores=1)
+    assert rec["bound"] is False and ("PermissionError" in rec["why"] or "nothing to narrow" in rec["why"])
+    assert A._ORIGINAL is None
