@@ -128,11 +128,8 @@ int sr_mlp_gemm_nt(const sr_gemm_args* host_args, void* stream);
 
 /* Layer chain: up to SR_CHAIN_MAX_LAYERS consecutive layer GEMMs of one or two independent networks (layer l of both side
  * by side in one grid) on a row count read from DEVICE memory: rows = *m_dev * m_mul <= m_cap * m_mul (every g[l][p].M is
- * ignored; g[l][p].group must equal m_mul).  g[l+1][p].A may be g[l][p].C.  Two forms:
- *   persistent == 0 : one launch per layer, grids sized for m_cap, workgroups beyond the live tiles return at once;
- *   persistent != 0 : ONE launch for the whole chain, layers separated by a device-wide barrier (barrier: one uint32 of
- *                     device scratch, zeroed by the call; error: int32 device flag set to 1 if the barrier had to give up --
- *                     the grid, 2 workgroups per CU, must be resident at once -- never cleared by the call).
+ * ignored; g[l][p].group must equal m_mul).  g[l+1][p].A may be g[l][p].C.  One launch per layer, grids sized for m_cap,
+ * workgroups beyond the live tiles return at once; no host synchronisation.
  * This is the MLP half of the reference's utils/FindSurfacePs.py:129-162 loop body on whatever number of rays is still
  * unfinished, without the host ever learning that number. */
 #define SR_CHAIN_MAX_LAYERS 10
@@ -141,10 +138,7 @@ typedef struct {
   int32_t nprob[SR_CHAIN_MAX_LAYERS];
   sr_gemm_args g[SR_CHAIN_MAX_LAYERS][2];
   const int32_t* m_dev; int32_t m_mul;
-  uint32_t* barrier; int32_t* error;
-  int32_t poll_mode;               /* how a waiting workgroup reads the arrival counter: 0 relaxed agent-scope load, 1 atomic read-modify-write */
-  int32_t m_cap;                   /* upper bound of *m_dev (sizes the grids of the per-layer form) */
-  int32_t persistent;
+  int32_t m_cap;                   /* upper bound of *m_dev (sizes the grids) */
 } sr_chain_args;
 int sr_mlp_chain(const sr_chain_args* host_args, void* stream);
 

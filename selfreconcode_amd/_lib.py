@@ -54,7 +54,7 @@ SR_CHAIN_MAX_LAYERS = 10
 
 class SrChainArgs(ctypes.Structure):
     _fields_ = [("nlayers", ctypes.c_int32), ("nprob", ctypes.c_int32 * SR_CHAIN_MAX_LAYERS), ("g", (SrGemmArgs * 2) * SR_CHAIN_MAX_LAYERS),
-                ("m_dev", _vp), ("m_mul", ctypes.c_int32), ("barrier", _vp), ("error", _vp), ("poll_mode", ctypes.c_int32), ("m_cap", ctypes.c_int32), ("persistent", ctypes.c_int32)]
+                ("m_dev", _vp), ("m_mul", ctypes.c_int32), ("m_cap", ctypes.c_int32)]
 
 
 class SrRefineArgs(ctypes.Structure):

@@ -108,7 +108,7 @@ int minv_bwd(const T* grads, const T* invs, T* outs, int64_t n, void* stream) {
 }  // namespace
 
 extern "C" {
-int sr_abi_version(void) { return 2; }
+int sr_abi_version(void) { return 3; }   // 3: sr_chain_args lost the fields of the one-launch chain form
 const char* sr_build_arch(void) { return "gfx950"; }
 // digest of the sources this library was built from (selfreconcode_amd/build.py passes it; the marker string is what build.py
 // looks for inside the .so to decide whether the library matches the tree -- no side file needed)

@@ -284,9 +284,12 @@ __device__ __forceinline__ void epilogue_interior_act(const sr_gemm_args& g, f32
 // ------------------------------------------------------------------------------------------------
 // C = epilogue(A[M,K] * B[N,K]^T)
 // One output tile (workgroup-wide).  `wg` is the linear tile index of this launch / layer; `smem` the workgroup's LDS
-// (Cfg::kLdsFloats floats).  Called once per workgroup by gemm_nt_kernel and in a loop by the persistent chain kernel.
-template <int WM, int WN, int TM, int TN, bool KTAIL = true>
-__device__ __forceinline__ void gemm_nt_tile(const sr_gemm_args& g, int wg, float* __restrict__ smem) {
+// (Cfg::kLdsFloats floats).  Called once per workgroup by gemm_nt_kernel and by mlp_layer_pair_kernel (row count from device memory).
+// (`probe(i)`: diagnostics hook of tools/nt_lab.hip -- cycle stamps at the end of the prologue (0), of the tile loop (1) and of the
+// epilogue (2); the product kernels pass the empty default, which compiles to nothing.)
+struct NoProbe { __device__ __forceinline__ void operator()(int) const {} };
+template <int WM, int WN, int TM, int TN, bool KTAIL = true, class Probe = NoProbe>
+__device__ __forceinline__ void gemm_nt_tile(const sr_gemm_args& g, int wg, float* __restrict__ smem, Probe probe = Probe()) {
   using C_ = Cfg<WM, WN, TM, TN>;
   auto As = [&](int buf) -> float* { return smem + buf * (C_::BM * LDSP); };
   auto Bs = [&](int buf) -> float* { return smem + 2 * C_::BM * LDSP + buf * (C_::BN * LDSP); };
@@ -353,6 +356,7 @@ __device__ __forceinline__ void gemm_nt_tile(const sr_gemm_args& g, int wg, floa
   la.template store<KTAIL>(As(0), 0, ra0); lb.template store<KTAIL>(Bs(0), 0, rb0);
   __syncthreads();
   read_frags(As(0), Bs(0), 0, fa0, fb0);
+  probe(0);
   auto step = [&](int t, f32x4 (&ain)[C_::kALoads], f32x4 (&bin)[C_::kBLoads], const f32x4 (&aout)[C_::kALoads],
                   const f32x4 (&bout)[C_::kBLoads]) {
     const int cur = t & 1;
@@ -389,6 +393,7 @@ __device__ __forceinline__ void gemm_nt_tile(const sr_gemm_args& g, int wg, floa
     if (t + 1 < nk) step(t + 1, ra1, rb1, ra0, rb0);
   }
   __syncthreads();   // the epilogue reuses the operand buffers
+  probe(1);
 
   // ---------------------------------------------------------------- epilogue
   float* stage = smem + wave * (TM * 32 * (TN * 32 + 4));   // the operand buffers are free after the last barrier
@@ -415,6 +420,7 @@ __device__ __forceinline__ void gemm_nt_tile(const sr_gemm_args& g, int wg, floa
       default: epilogue<WM, WN, TM, TN, 4>(g, acc, m0, n0, wm, wn, li, kh, stage); break;
     }
   }
+  probe(2);
 }
 
 template <int WM, int WN, int TM, int TN, bool KTAIL>
@@ -428,60 +434,10 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
 // (Tried in round 4: the same tiles walked by a RESIDENT grid of 512 workgroups with a stride loop -- 135.4 against 135.3 TFLOP/s on
 // 262144 x 512 x 512: retiring a workgroup and placing a fresh one is not where the time goes.)
 
-// ------------------------------------------------------------------------------------------------
-// Persistent layer chain: ONE launch runs up to SR_CHAIN_MAX_LAYERS consecutive layers of one or two independent MLPs
-// (e.g. layer l of the SDF and of the deformation network side by side) on a row count that lives in DEVICE memory.
-// The workgroups of a resident grid (2 per CU) walk the tiles of a layer with a stride of the grid size and meet at a
-// device-wide barrier before the next layer reads what this one wrote.  Written for the ray refiner, whose batch shrinks
-// from step to step (the live count is produced by the compaction kernel of the previous step and never visits the host)
-// and whose ~6k rows make a layer too short to amortise a launch: 14 + 14 layer launches per Newton step become 2.
-__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t target, int32_t* error, int poll_mode) {
-  __syncthreads();
-  bool ok = true;
-  if (threadIdx.x == 0) {
-    // ONE release (write back this XCD's L2) before the arrival and ONE acquire (invalidate it) after the wait.  The polls in
-    // between are relaxed: an acquire load invalidates the L2 every time it is issued, under the feet of the workgroups of
-    // the same XCD that are still computing tiles of this layer (measured: the chain ran 4x slower that way).
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    long long spins = 0;
-    while ((poll_mode ? __hip_atomic_fetch_add(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                      : __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
-      if (poll_mode) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(16);
-      if (++spins > (1ll << 23)) {                     // a workgroup never arrived (grid not co-resident): give up, loudly
-        __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = false;
-        break;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  ok = __syncthreads_and(ok);
-  return ok;
-}
-
 using ChainCfg = Cfg<2, 2, 1, 1>;      // 64x64 tiles: the refiner's few thousand rows give ~100 row panels
-__global__ __launch_bounds__(ChainCfg::kThreads) __attribute__((amdgpu_waves_per_eu(2))) void mlp_chain_kernel(sr_chain_args c) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int M = *c.m_dev * c.m_mul;
-  for (int l = 0; l < c.nlayers; ++l) {
-    int ntiles[2] = {0, 0};
-    if (M > 0) {
-      for (int p = 0; p < c.nprob[l]; ++p) {
-        const sr_gemm_args& g = c.g[l][p];
-        ntiles[p] = ((M + ChainCfg::BM - 1) / ChainCfg::BM) * ((g.N + (g.mode == SR_EPI_FWD ? g.naux_fwd : 0) + ChainCfg::BN - 1) / ChainCfg::BN);
-      }
-    }
-    for (int t = blockIdx.x; t < ntiles[0] + ntiles[1]; t += gridDim.x) {
-      const int p = t < ntiles[0] ? 0 : 1;
-      sr_gemm_args g = c.g[l][p];
-      g.M = M;
-      gemm_nt_tile<2, 2, 1, 1>(g, t - (p ? ntiles[0] : 0), smem);
-      __syncthreads();                                 // the next tile reuses the LDS image
-    }
-    if (l + 1 < c.nlayers && !grid_barrier(c.barrier, (uint32_t)(l + 1) * gridDim.x, c.error, c.poll_mode)) return;
-  }
-}
+// (Rounds 2-5 also carried a one-launch form of a layer chain -- a resident grid walking the tiles of every layer with a device-wide
+// barrier between layers.  It lost every measurement: ~35 us per barrier against ~13 us per dependent launch, and a cooperative grid
+// cannot get residency next to the 128x128 tiles of the stream it runs beside.  Removed in round 6.)
 
 // ------------------------------------------------------------------------------------------------
 // dW[N,K] = sum_r Z[r,N]^T A[r,K]   (split over r into `splits` slabs, reduced below)
@@ -545,12 +501,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
   // The ISA of the single form had 192 VALU operations per step next to its 64 MFMAs (16 quarter-rate v_mul_lo_u32, 32 selects, 26
   // bias adds in every workgroup although only the k0 == 0 column of tiles folds a bias gradient): the kernel ran at 118 TFLOP/s where
   // the NT tile code (12 VALU operations per step) reaches 135.
-  const float* zbase[TLZ];
-  const float* xbase[TLX];
+  // (round 6) a full-tile load is `global_load_dwordx4 v, v_off, s[base]`: the tile's first row as a 64-bit SCALAR base, the thread's
+  // place inside a tile as a 32-bit byte offset that never changes -- no per-lane 64-bit add in front of every load (the step had 16 of
+  // them).  A tile spans at most TBR rows of the wider operand, far below 4 GB.
+  uint32_t zbyte[TLZ], xbyte[TLX];
 #pragma unroll
-  for (int j = 0; j < TLZ; ++j) zbase[j] = zcol + (int64_t)(lrz + j * (256 / ZT)) * g.ldz;
+  for (int j = 0; j < TLZ; ++j) zbyte[j] = (uint32_t)(((int64_t)(lrz + j * (256 / ZT)) * g.ldz + (zcol - g.Z)) * 4);
 #pragma unroll
-  for (int j = 0; j < TLX; ++j) xbase[j] = xcol + (int64_t)(lrx + j * (256 / XT)) * g.lda;
+  for (int j = 0; j < TLX; ++j) xbyte[j] = (uint32_t)(((int64_t)(lrx + j * (256 / XT)) * g.lda + (xcol - g.A)) * 4);
   const int last_full = r_end - TBR;                  // start row of the slab's last full tile (TAIL = false)
   auto load = [&](int r0, auto tail) {
     if constexpr (decltype(tail)::value) {
@@ -568,11 +526,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
       }
     } else {
       const int rc = r0 < last_full ? r0 : last_full;                       // (uniform)
-      const int64_t oz = (int64_t)rc * g.ldz, ox = (int64_t)rc * g.lda;     // (uniform: scalar multiplies)
+      const char* zrow = reinterpret_cast<const char*>(g.Z + (int64_t)rc * g.ldz);   // (uniform: scalar arithmetic)
+      const char* xrow = reinterpret_cast<const char*>(g.A + (int64_t)rc * g.lda);
 #pragma unroll
-      for (int j = 0; j < TLZ; ++j) rz[j] = *reinterpret_cast<const f32x4*>(zbase[j] + oz);
+      for (int j = 0; j < TLZ; ++j) rz[j] = *reinterpret_cast<const f32x4*>(zrow + zbyte[j]);
 #pragma unroll
-      for (int j = 0; j < TLX; ++j) rx[j] = *reinterpret_cast<const f32x4*>(xbase[j] + ox);
+      for (int j = 0; j < TLX; ++j) rx[j] = *reinterpret_cast<const f32x4*>(xrow + xbyte[j]);
     }
   };
   auto store = [&](int buf, int r0, auto tail) {
@@ -600,15 +559,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
   };
 
-  // fragments of 8 k-steps (16 rows): one dword per k-step and 32-wide block
+  // fragments of 8 k-steps (16 rows).  The two 32-wide blocks of a wave's 64 columns are INTERLEAVED -- block a holds the columns
+  // 2 i + a (i = 0..31) -- so that one 8-byte LDS read gives a lane the operands of both blocks for a k-step: 32 ds_read_b64 per step
+  // where the contiguous blocks (columns i and 32 + i) took 64 ds_read_b32, next to the step's 64 MFMAs.  (Lanes 0..31 of a read cover 64
+  // consecutive dwords: conflict-free.)  Only the column index of the final stores knows about the interleave.
   constexpr int HS = TBR / 4;   // k-steps per half tile
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   float z0a[HS], z1a[HS], x0a[HS], x1a[HS], z0b[HS], z1b[HS], x0b[HS], x1b[HS];
-  const int zoff = kh * C::ZLD + wm * 64 + li, xoff = kh * C::XLD + wn * 64 + li;
+  const int zoff = kh * C::ZLD + wm * 64 + 2 * li, xoff = kh * C::XLD + wn * 64 + 2 * li;
   auto read_half = [&](int buf, int half, float (&z0)[HS], float (&z1)[HS], float (&x0)[HS], float (&x1)[HS]) {
     const float* zb = Zs(buf) + zoff + half * HS * 2 * C::ZLD;
     const float* xb = Xs(buf) + xoff + half * HS * 2 * C::XLD;
 #pragma unroll
-    for (int e = 0; e < HS; ++e) { z0[e] = zb[2 * e * C::ZLD]; z1[e] = zb[2 * e * C::ZLD + 32]; x0[e] = xb[2 * e * C::XLD]; x1[e] = xb[2 * e * C::XLD + 32]; }
+    for (int e = 0; e < HS; ++e) {
+      const f32x2 z = *reinterpret_cast<const f32x2*>(zb + 2 * e * C::ZLD), x = *reinterpret_cast<const f32x2*>(xb + 2 * e * C::XLD);
+      z0[e] = z.x; z1[e] = z.y; x0[e] = x.x; x1[e] = x.y;
+    }
   };
   auto mfma_half = [&](const float (&z0)[HS], const float (&z1)[HS], const float (&x0)[HS], const float (&x1)[HS]) {
 #pragma unroll
@@ -660,8 +626,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
 #pragma unroll
-      for (int i = 0; i < 4 * HS - 2 * (TLZ + TLX); ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      for (int i = 0; i < HS; ++i) {                 // the half's 2 HS 8-byte fragment reads leave the compiler as HS ds_read2_b64
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -688,8 +654,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     float* red = Zs(0);
     if (wn == 0) {
       const bool use = kh == 0 || g.group == 1;
-      red[kh * ZW + wm * 64 + li] = use ? bsum0 : 0.f;
-      red[kh * ZW + wm * 64 + 32 + li] = use ? bsum1 : 0.f;
+      red[kh * ZW + wm * 64 + 2 * li] = use ? bsum0 : 0.f;          // (interleaved blocks: column 2 li + a)
+      red[kh * ZW + wm * 64 + 2 * li + 1] = use ? bsum1 : 0.f;
     }
     __syncthreads();
     if (threadIdx.x < ZW && n0 + threadIdx.x < g.N) g.db_partial[(int64_t)split * g.N + n0 + threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + ZW];
@@ -699,11 +665,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const int col = k0 + wn * 64 + b * 32 + li;
+      const int col = k0 + wn * 64 + 2 * li + b;                    // interleaved blocks (see read_half)
       if (col >= g.K) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = n0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int row = n0 + wm * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + a;
         if (row < g.N) out[(int64_t)row * g.lddw + col] = acc[a][b][r];
       }
     }
@@ -819,21 +785,13 @@ int sr_mlp_gemm_nt(const sr_gemm_args* a, void* stream) {
     // cost = ceil(workgroups / 256) * bm * bn / eff, eff = measured large-M rate of the configuration relative to 128x128.
     // (M = 6144, N = 512: 64x64 gives 3 tiles/CU = 12.3k, 64x128 2 tiles/CU = 16.4k, 128x128 1 tile on 192 CUs = 16.4k;
     // measured 31.5 / 39.9 / 45 us.)
-    static const int forced = getenv("SR_NT_CFG") ? atoi(getenv("SR_NT_CFG")) : 0;   // tuning switch
-    int pick = forced;
-    static const int smallk = getenv("SR_NT_SMALLK") ? atoi(getenv("SR_NT_SMALLK")) : 0;   // tuning switch: tile configuration for K <= 64
-    if (!pick && smallk && g.K <= 64) pick = smallk;
-    if (!pick) {
-      const double c[3] = {cost(64, 64, 0.92), cost(64, 128, 0.94), cost(128, 128, 1.0)};
-      pick = 1;
-      for (int i = 1; i < 3; ++i) if (c[i] < c[pick - 1]) pick = i + 1;
-    }
+    // (256x128 and 128x256 tiles with 8 waves were measured in rounds 3-4 and lose: one workgroup per CU.)
+    const double c[3] = {cost(64, 64, 0.92), cost(64, 128, 0.94), cost(128, 128, 1.0)};
+    int pick = 1;
+    for (int i = 1; i < 3; ++i) if (c[i] < c[pick - 1]) pick = i + 1;
     switch (pick) {
       case 1: SR_NT_LAUNCH(2, 2, 1, 1); break;
       case 2: SR_NT_LAUNCH(2, 2, 1, 2); break;
-      case 3: SR_NT_LAUNCH(2, 2, 2, 2); break;
-      case 4: SR_NT_LAUNCH(4, 2, 2, 2); break;      // 256x128, 8 waves (tuning switch only)
-      case 5: SR_NT_LAUNCH(2, 4, 2, 2); break;      // 128x256, 8 waves (tuning switch only)
       default: SR_NT_LAUNCH(2, 2, 2, 2); break;
     }
   }
@@ -858,20 +816,8 @@ __global__ __launch_bounds__(ChainCfg::kThreads) __attribute__((amdgpu_waves_per
   else { g1.M = M; if (g1.K % BK) gemm_nt_tile<2, 2, 1, 1, true>(g1, t - t0, smem); else gemm_nt_tile<2, 2, 1, 1, false>(g1, t - t0, smem); }
 }
 
-static int chain_grid_size() {
-  static int grid = 0;
-  if (!grid) {
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mlp_chain_kernel, ChainCfg::kThreads, ChainCfg::kLdsFloats * sizeof(float)) != hipSuccess) return 0;
-    if (per_cu > 2) per_cu = 2;
-    grid = cus * per_cu;
-  }
-  return grid;
-}
-
 int sr_mlp_chain(const sr_chain_args* a, void* stream) {
-  if (!a || a->nlayers < 1 || a->nlayers > SR_CHAIN_MAX_LAYERS || !a->m_dev || !a->barrier || !a->error || a->m_mul < 1) return SR_EINVAL;
+  if (!a || a->nlayers < 1 || a->nlayers > SR_CHAIN_MAX_LAYERS || !a->m_dev || a->m_mul < 1 || a->m_cap <= 0) return SR_EINVAL;
   for (int l = 0; l < a->nlayers; ++l) {
     if (a->nprob[l] < 1 || a->nprob[l] > 2) return SR_EINVAL;
     for (int p = 0; p < a->nprob[l]; ++p) {
@@ -883,32 +829,24 @@ int sr_mlp_chain(const sr_chain_args* a, void* stream) {
       if ((g.mode == SR_EPI_BWD && g.act != SR_ACT_NONE && !g.aux) || (g.mode == SR_EPI_FWD && g.naux_fwd > 0 && !g.aux)) return SR_EINVAL;
     }
   }
-  if (!a->persistent) {
-    // one launch per layer (pair): measured 12.6 us per dependent launch against ~35 us per device-wide barrier of the persistent
-    // form (512 workgroups each writing back and invalidating their XCD's L2), see profiles/r02_chain_bench.txt
-    if (a->m_cap <= 0) return SR_EINVAL;
-    const int64_t rows = sr_cdiv((int64_t)a->m_cap * a->m_mul, ChainCfg::BM);
-    for (int l = 0; l < a->nlayers; ++l) {
-      int64_t tiles = 0;
-      for (int p = 0; p < a->nprob[l]; ++p) {
-        const sr_gemm_args& g = a->g[l][p];
-        tiles += rows * sr_cdiv(g.N + (g.mode == SR_EPI_FWD ? g.naux_fwd : 0), ChainCfg::BN);
-      }
-      hipLaunchKernelGGL(mlp_layer_pair_kernel, dim3((unsigned)tiles), dim3(ChainCfg::kThreads), ChainCfg::kLdsFloats * sizeof(float), (hipStream_t)stream,
-                         a->g[l][0], a->g[l][a->nprob[l] > 1 ? 1 : 0], a->nprob[l], a->m_dev, a->m_mul);
+  // one launch per layer (pair): grids sized for the capacity row count, workgroups past the tiles of the live count return at once;
+  // consecutive layers are ordered by the stream (~13 us per dependent launch at 2k rows, the layer's own duration)
+  const int64_t rows = sr_cdiv((int64_t)a->m_cap * a->m_mul, ChainCfg::BM);
+  for (int l = 0; l < a->nlayers; ++l) {
+    int64_t tiles = 0;
+    for (int p = 0; p < a->nprob[l]; ++p) {
+      const sr_gemm_args& g = a->g[l][p];
+      tiles += rows * sr_cdiv(g.N + (g.mode == SR_EPI_FWD ? g.naux_fwd : 0), ChainCfg::BN);
     }
-    return sr_launch_status();
+    hipLaunchKernelGGL(mlp_layer_pair_kernel, dim3((unsigned)tiles), dim3(ChainCfg::kThreads), ChainCfg::kLdsFloats * sizeof(float), (hipStream_t)stream,
+                       a->g[l][0], a->g[l][a->nprob[l] > 1 ? 1 : 0], a->nprob[l], a->m_dev, a->m_mul);
   }
-  const int grid = chain_grid_size();
-  if (grid <= 0) return SR_ELAUNCH;
-  if (hipMemsetAsync(a->barrier, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return SR_ELAUNCH;
-  hipLaunchKernelGGL(mlp_chain_kernel, dim3(grid), dim3(ChainCfg::kThreads), ChainCfg::kLdsFloats * sizeof(float), (hipStream_t)stream, *a);
   return sr_launch_status();
 }
 
 int64_t sr_mlp_gemm_tn_workspace_floats(int32_t R, int32_t N, int64_t lddw, int32_t* splits_out) {
   const int tiles = tn_narrow(N, lddw) ? (int)sr_cdiv(N, 256) : (int)(sr_cdiv(N, 128) * sr_cdiv(lddw, 128));
-  static const int target = getenv("SR_TN_BLOCKS") ? atoi(getenv("SR_TN_BLOCKS")) : 512;   // tuning switch
+  const int target = 512;
   int splits = (int)sr_cdiv(target, tiles);           // two workgroups per CU are resident (LDS): one full wave of the chip; every
                                                       // further slab costs a 64 KB partial tile written and read again
   const int max_splits = (int)sr_cdiv(R, 384);       // at least 384 rows (12 steps) per split

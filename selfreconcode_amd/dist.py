@@ -15,7 +15,10 @@ def init_from_env(device_type="cuda", bind_cpus=False):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns (rank, world, device).
     `bind_cpus`: confine the rank's host threads to a group of cores of its GPU's NUMA node, one group per local rank
     (selfreconcode_amd/affinity.py: the step is ~2 600 launches issued by threads that hand over to each other; at one frame per rank the
-    host paces it)."""
+    host paces it).  SIDE EFFECT: the mask narrows EVERY thread of the process, existing and future -- torch's intra-op / OpenMP pool (sized
+    for the whole machine before the call) and DataLoader workers forked later share the 8 cores + SMT siblings.  Opt-in for that reason:
+    a training loop with CPU-side data loading should leave it off, widen it (SR_BIND_CORES) or size its pools to the group
+    (`torch.set_num_threads(len(dist.PLACEMENT["cpus"]))` if the record lists them)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

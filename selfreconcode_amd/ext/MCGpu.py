@@ -4,16 +4,14 @@
         -> [verts[V,3] f32, faces[F,3] int64]
     mc_init(device_id)
 
-Error convention kept from the reference: wrong dtype / a device index outside [0, 8) / non-positive dims return an
-EMPTY LIST (MCGpu.cpp:41-48); non-GPU / non-contiguous input raises (the CHECK_INPUT macro, :3-5,31).  Unlike
-the reference there is no per-device singleton with unchecked 5% scratch: workspace and outputs are
-sized per call, on the caller's stream, and the output order is deterministic.
+Error convention kept from the reference: wrong dtype / non-positive dims return an EMPTY LIST (MCGpu.cpp:41-48); non-GPU /
+non-contiguous input raises (the CHECK_INPUT macro, :3-5,31).  The reference also returns [] for a device index outside [0, 8)
+(:43-45) -- the size of its fixed array of per-device singletons.  There is no such array here (workspace and outputs are sized
+per call, on the caller's stream, and the output order is deterministic), so every device index works: on a node that exposes more
+than 8 logical devices (CPX partitions, 16-GPU boxes) the reference's limit would only turn the first remesh into an unpack error.
 """
 import torch
 from .. import _lib
-
-
-MAX_DEVICES = 8
 
 
 def mc_init(device_id):
@@ -26,8 +24,6 @@ def mc_gpu(sdfs, xstep=1.0, ystep=1.0, zstep=1.0, xmin=0.0, ymin=0.0, zmin=0.0, 
     if not sdfs.is_contiguous():
         raise RuntimeError("sdfs must be contiguous")
     if sdfs.dtype != torch.float32 or sdfs.dim() != 3:
-        return []
-    if not 0 <= sdfs.get_device() < MAX_DEVICES:        # MCGpu.cpp:43-45 (the reference keeps one singleton per device of an 8-GPU node)
         return []
     nx, ny, nz = sdfs.shape
     if nx <= 0 or ny <= 0 or nz <= 0:

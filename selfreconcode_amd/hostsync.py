@@ -3,15 +3,12 @@
 `mask.nonzero()` is a count kernel, a small device-to-host copy and a blocking wait of the calling thread for that copy.  This module
 is the one place the iteration's round trips go through (two per iteration with the fused selection, six without:
 `nonzero_many` carries several counts in one), so that they can be traced (TRACE: tools/host_profile.py stamps the
-device clock when the count copy is issued and the host clock when the count arrives) and so that the wait can be switched to a
-polling one (SR_HOST_POLL=1: asynchronous copy to pinned memory, hipEventQuery in a loop, then torch.nonzero_static with the size
-known).  Measured on MI355X / ROCm 7.2: both forms return within ~20 us of the count being ready on the GPU; what looked like a
-10 ms wake-up latency of the blocking form was the host running a whole iteration ahead of the GPU (profiles/r03_host_vs_gpu.txt).
-Default: torch's own nonzero (the polling loop occupies a core for nothing)."""
+device clock when the count copy is issued and the host clock when the count arrives).  (A polling form -- asynchronous copy to
+pinned memory, hipEventQuery in a loop -- returned within the same ~20 us of the count being ready as torch's blocking wait and was
+removed in round 6; what had looked like a 10 ms wake-up latency was the host running an iteration ahead, profiles/r03_host_vs_gpu.txt.)"""
 import os
 import torch
 
-POLL = os.environ.get("SR_HOST_POLL", "0") != "0"
 TRACE = None        # diagnostics (tools/host_profile.py): callable(label), called when the count copy has been issued and when the host has it
 _pinned = {}
 
@@ -41,7 +38,7 @@ def count_to_host(count):
 
 def nonzero(mask, as_tuple=False):
     """mask.nonzero(as_tuple=...) for a bool CUDA tensor: same rows, same (lexicographic) order."""
-    if not ((POLL or TRACE is not None) and mask.is_cuda):
+    if not (TRACE is not None and mask.is_cuda):
         return mask.nonzero(as_tuple=as_tuple)
     n = count_to_host(mask.count_nonzero())
     idx = torch.nonzero_static(mask, size=n)
@@ -53,23 +50,9 @@ def nonzero_many(masks, also=()):
     made with their sizes known (torch.nonzero_static: no synchronisation).  Same rows, same order as mask.nonzero().view(-1).
     `also`: 0-dim integer device tensors that ride along; with them the result is (lists, their values as ints)."""
     counts = torch.stack([m.count_nonzero() for m in masks] + [a.to(torch.int64).view(()) for a in also])
-    if POLL and counts.is_cuda:
-        key = (counts.device.index, torch.cuda.current_stream(counts.device).cuda_stream, int(counts.numel()))
-        buf = _pinned.get(key)
-        if buf is None:
-            buf = _pinned[key] = torch.zeros(int(counts.numel()), dtype=torch.int64).pin_memory()
-        buf.copy_(counts, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        if TRACE is not None:
-            TRACE('count copy issued')
-        while not ev.query():
-            pass
-        n = buf.tolist()
-    else:
-        if TRACE is not None:
-            TRACE('count copy issued')
-        n = counts.tolist()
+    if TRACE is not None:
+        TRACE('count copy issued')
+    n = counts.tolist()
     if TRACE is not None:
         TRACE('count on the host')
     lists = [torch.nonzero_static(m, size=int(k)).view(-1) for m, k in zip(masks, n)]

@@ -166,15 +166,10 @@ def _gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, group, act, mode, out_scale=
     _lib.call("sr_mlp_gemm_nt", ctypes.byref(a), _lib.stream_of(C))
 
 
-def _gemm_tn(Z, ldz, A, lda, R, N, K, lddw, group=1, dW=None, db=None, accumulate=False, shared_machine=False):
-    """dW [N, lddw] (+)= Z[:, :N]^T A[:, :K] and db [N] (+)= sum of the primal rows of Z (deterministic slab reductions).
-    `shared_machine`: the launch is expected to run next to another stream's GEMMs (the weight-gradient stream of deferred mode):
-    half as many row slabs (one workgroup per CU instead of two: measured 50.2 -> 49.3 ms / iteration; alone on the machine two per
-    CU are ~5 % faster)."""
+def _gemm_tn(Z, ldz, A, lda, R, N, K, lddw, group=1, dW=None, db=None, accumulate=False):
+    """dW [N, lddw] (+)= Z[:, :N]^T A[:, :K] and db [N] (+)= sum of the primal rows of Z (deterministic slab reductions)."""
     splits = ctypes.c_int32(0)
     ws = _lib.raw("sr_mlp_gemm_tn_workspace_floats")(R, N, lddw, ctypes.byref(splits))
-    if shared_machine and splits.value > 1:
-        splits = ctypes.c_int32((splits.value + 1) // 2)         # (the workspace was sized for the larger count)
     if dW is None:
         dW = torch.empty((N, lddw), dtype=torch.float32, device=Z.device)
     partial = torch.empty((max(int(ws), 1) + splits.value * N,), dtype=torch.float32, device=Z.device)
@@ -252,11 +247,9 @@ def _bias_segments(b0, R, group):
 # weight-gradient workgroups fill its tails.  Only in deferred mode (the results land in the per-layer buffers, nobody reads them
 # before flush_param_grads, which joins the stream); all weight-gradient launches share ONE stream, so the accumulation order into
 # a buffer is the program order -- results are bit-identical to the one-stream schedule.
-TN_SIDE_STREAM = os.environ.get("SR_TN_STREAM", "1") != "0"
-# Row slabs of the deferred weight-gradient launches: all of them (two workgroups per CU) since round 5 -- with the ray branch and the
-# template term's backward moved under the refiner the weight-gradient stream is what the tail of the big backward waits for (45.0 ->
-# 44.2 ms / iteration); SR_TN_HALF_SLABS=1 restores round 3's half count (one workgroup per CU next to the other stream's two).
-TN_HALF_SLABS = os.environ.get("SR_TN_HALF_SLABS", "0") != "0"
+TN_SIDE_STREAM = True          # (module attribute: tests compare the one- and two-stream schedules bit for bit)
+# (Row slabs of the deferred weight-gradient launches: all of them, two workgroups per CU -- since round 5 the weight-gradient stream is
+# what the tail of the big backward waits for; rounds 3-4 ran half the count.)
 _TN_STREAMS = {}
 _TN_PENDING = set()
 
@@ -318,13 +311,11 @@ def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_g
                     with torch.cuda.stream(side):
                         if DEBUG_TN_DELAY_MS:
                             _debug_delay(A0.device, DEBUG_TN_DELAY_MS)
-                        _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group, dW=sink[0], db=sink[1], accumulate=sink[2],
-                                 shared_machine=TN_HALF_SLABS)
+                        _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group, dW=sink[0], db=sink[1], accumulate=sink[2])
                     Zbar.record_stream(side); X.record_stream(side)      # both may be freed by the main stream's owner before the side stream has read them
                     _TN_PENDING.add(str(A0.device))
                 elif sink is not None:        # accumulate straight into the per-step gradient buffers (no autograd traffic)
-                    _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group, dW=sink[0], db=sink[1], accumulate=sink[2],
-                             shared_machine=TN_HALF_SLABS)
+                    _gemm_tn(Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group, dW=sink[0], db=sink[1], accumulate=sink[2])
                 elif l == 0 and seg is not None:
                     # segmented first-layer bias: the weight gradient is the sum over the segments (accumulated launch by launch, in
                     # segment order), the bias gradient one row per segment
@@ -647,7 +638,7 @@ def refresh_packs(lins):
         torch.autograd.graph.increment_version([t for e, _, _, _ in chunk for t in (e["W"], e["WT"], e["norms"]) if t is not None])
 
 
-PLAIN_PACKS = os.environ.get("SR_PLAIN_PACKS", "1") != "0"
+PLAIN_PACKS = True
 
 
 def pack_linear(lin):

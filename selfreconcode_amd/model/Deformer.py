@@ -11,8 +11,8 @@ from ..mlp_engine import MLPSpec, mlp_apply, pad_cols, pad4, pack_linear
 from ..utils.utils import resolve_band_weights
 
 
-BATCH_FRAMES = os.environ.get('SR_BATCH_FRAMES', '1') != '0'             # hoisted path: one batch over all frames instead of one MLP pass per frame
-HOIST_FRAME_CODE = os.environ.get('SR_HOIST_FRAME_CODE', '1') != '0'     # frame-major batches: per-frame code product out of the deformer's first-layer GEMM (MLPTranslator.hoisted_first_layer)
+BATCH_FRAMES = True             # hoisted path: one batch over all frames instead of one MLP pass per frame
+HOIST_FRAME_CODE = True     # frame-major batches: per-frame code product out of the deformer's first-layer GEMM (MLPTranslator.hoisted_first_layer)
 
 
 _EYE3 = {}

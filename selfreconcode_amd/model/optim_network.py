@@ -34,7 +34,6 @@ from ..utils.FindSurfacePs import FindSurfacePs, OptimizeSurfacePs
 from .CameraMine import RectifiedPerspectiveCameras
 
 
-SPLIT_SAMPLE_TERMS = os.environ.get('SR_SPLIT_SAMPLE_TERMS', '0') != '0'    # see forward(): refiner-independent part of the sampled terms first
 # The ray branch -- everything that hangs on the CONVERGED rays: colour + normal terms, their backward, the implicit-gradient pass
 # (network.py:599-639, 702-814) -- is a chain of a few hundred SMALL launches (1-5k rows) paced by the host, and nothing on the
 # main stream needs its results before the optimizer step.  With the switch on it runs on the high-priority side stream NEXT TO the
@@ -188,6 +187,8 @@ class OptimNetwork(nn.Module):
         sdfs = engine.forward()
         out = MCGpu.mc_gpu(sdfs[0, 0].permute(2, 1, 0).contiguous(), engine.spacing_x, engine.spacing_y, engine.spacing_z,
                            engine.bx, engine.by, engine.bz, balance_value)
+        if len(out) != 2:                      # (mc_gpu's empty-list convention for a wrong dtype / non-positive dims, MCGpu.cpp:41-48)
+            raise RuntimeError(f"mc_gpu rejected the SDF volume (dtype {sdfs.dtype}, shape {tuple(sdfs.shape)}): float32 [1,1,X,Y,Z] expected")
         verts, faces = out
         return verts, faces
 
@@ -326,8 +327,7 @@ class OptimNetwork(nn.Module):
             # high priority: the ray selection on this stream is a handful of tiny kernels with a host round trip after each
             # (nonzero); at equal priority each of them queues behind the template branch's thousands of GEMM workgroups and the
             # refiner that follows is not even issued before that branch has drained
-            prio = int(os.environ.get('SR_SIDE_STREAM_PRIORITY', '-1'))
-            st[key] = torch.cuda.Stream(device=device, priority=prio)
+            st[key] = torch.cuda.Stream(device=device, priority=-1)
         return st[key]
 
     def _seed_rays(self, defTmpVs, cameras, H, W, canonical=None):
@@ -357,7 +357,19 @@ class OptimNetwork(nn.Module):
 
     # ------------------------------------------------------------------ one training iteration
     def forward(self, datas, sample_pix, ratio, frame_ids, root=None, rand=None, debug=None, **kwargs):
-        """`rand` (extension): dict of pre-drawn random tensors (ray_select, vert_select, vert_select2, eik_local, eik_global,
+        """One training iteration; the returned loss is back-propagated by the caller, then `propagateTmpPsGrad` is called -- the
+        reference's loop order (train.py:160-170): zero_grad -> forward -> loss.backward() -> propagateTmpPsGrad -> optimizer step.
+
+        CONTRACT of the default (eager) schedule.  Three parts of the loss are back-propagated INSIDE this call -- the mask / consistency
+        terms (as in the reference, network.py:683-688), and with EAGER_TEMPLATE_TERM / EAGER_RAY_BRANCH also pc_weight * mean|f(TmpVs)| and
+        the colour + normal terms -- and enter the returned loss as VALUES.  Their parameter gradients are therefore already deposited when
+        this call returns, with weight 1: (a) `zero_grad()` must come BEFORE forward(), never between forward() and backward()
+        (propagateTmpPsGrad raises if the per-frame gradients deposited here have been discarded); (b) scaling the returned loss (gradient
+        accumulation `loss / k`, a GradScaler) scales only the terms the outer backward carries -- scale the learning rate instead, or run
+        with SR_EAGER_TEMPLATE_TERM=0 SR_EAGER_RAY_BRANCH=0, which leaves ONE backward of the total loss as the reference writes it;
+        (c) `torch.autograd.grad(loss, ...)` sees only the outer terms, for the same reason.
+
+        `rand` (extension): dict of pre-drawn random tensors (ray_select, vert_select, vert_select2, eik_local, eik_global,
         regu_local; each may be longer than needed, the head is used) so that a parity test feeds both sides the same numbers;
         `rand['refined'] = (points, flags)` replaces the refiner's output for the selected rays (its |f| < 5e-5 acceptance flips
         on single ulps: tests compare the refiner separately and everything after it on identical ray sets);
@@ -563,11 +575,8 @@ class OptimNetwork(nn.Module):
         else:
             join_vertex_lists = lambda: main.wait_event(selected)       # (made with the ray selection, on its stream)
         # The eikonal and deformation-regulariser samples are [refined ray points ; a random subset of the template vertices] (+ uniform
-        # samples): the vertex / uniform part does not depend on the refiner, which -- 200 dependent launches of a few thousand rows each,
-        # under the template branch's large kernels -- finishes ~2.5 ms AFTER the main stream has drained the template branch
-        # (tools/host_profile.py).  So each term is evaluated as two batches: the refiner-independent one is queued before the main
-        # stream waits for the refiner, the ray one after it; the means are recombined with their counts (SPLIT_SAMPLE_TERMS = False:
-        # one batch each, as the reference writes it).
+        # samples), one batch each as the reference writes it.  (Rounds 3-5 carried a split form -- the refiner-independent part first --
+        # that never paid: the refiner then shares the machine and ends later.)
         self._debug_delay('main_before_join')
         join_vertex_lists()
         for t in (eik_idx, regu_idx):
@@ -576,21 +585,13 @@ class OptimNetwork(nn.Module):
         poses, trans, d_cond, rendcond = self.dataset.get_grad_parameters(frame_ids, device)     # (the inner backward freed the first set's graph)
         defconds = [d_cond, [poses, trans]]
         nr = batch_inds.shape[0]
-        split = SPLIT_SAMPLE_TERMS and nr > 0 and eik_idx.numel() > 0
         n_base = nr + eik_idx.shape[0]
         n_glob = n_base // 6
         nl = rand['eik_local'][:n_base] if 'eik_local' in rand else torch.randn(n_base, 3, device=device)
         ng = rand['eik_global'][:n_glob] if 'eik_global' in rand else torch.rand(n_glob, 3, device=device)
-        use_regu_split = split and use_regu and regu_idx.numel() > 0
         if use_regu:
             n_regu = nr + regu_idx.shape[0]
             nl2 = rand['regu_local'][:n_regu] if 'regu_local' in rand else torch.randn(n_regu, 3, device=device)
-        if split:
-            eikA_pts = torch.cat([self.TmpVs.detach()[eik_idx] + nl[nr:] * 0.01, ng * (1.8 * 2) - 1.8], dim=0)
-            eikA = self._eikonal_mean(eikA_pts, ratio)
-        if use_regu_split:
-            vA = self.TmpVs.detach()[regu_idx]
-            defA = self._def_regu_mean(torch.cat([vA, vA + nl2[nr:] * 0.01], dim=0), d_cond, N, ratio)
         self._mark('vertex-part samples issued')
 
         main.wait_stream(side)
@@ -605,17 +606,10 @@ class OptimNetwork(nn.Module):
             debug.update(initTmpPs=initTmpPs, check=check, rays=rays)
 
         # --- eikonal (network.py:543-549; sample_points utils.py:74-84)
-        if split:
-            eikB_pts = initTmpPs + nl[:nr] * 0.01
-            eikB = self._eikonal_mean(eikB_pts, ratio)
-            nA, nB = eikA_pts.shape[0], eikB_pts.shape[0]
-            grad_loss = eikA * (float(nA) / float(nA + nB)) + eikB * (float(nB) / float(nA + nB))
-            self._eik_pts = torch.cat([eikB_pts.detach(), eikA_pts.detach()], dim=0)      # the reference's order: rays, vertices, uniform
-        else:
-            base = torch.cat([initTmpPs, self.TmpVs.detach()[eik_idx]], dim=0)
-            pts = torch.cat([base + nl * 0.01, ng * (1.8 * 2) - 1.8], dim=0)
-            self._eik_pts = pts.detach()
-            grad_loss = self._eikonal_mean(pts, ratio)
+        base = torch.cat([initTmpPs, self.TmpVs.detach()[eik_idx]], dim=0)
+        pts = torch.cat([base + nl * 0.01, ng * (1.8 * 2) - 1.8], dim=0)
+        self._eik_pts = pts.detach()
+        grad_loss = self._eikonal_mean(pts, ratio)
         self._mark('eikonal issued')
         self.info['grad_loss'] = grad_loss.detach()
         wpool = srdist.pooled_mean_weight(n_base, device)      # N > 1 ranks: pooled mean over the points of all ranks (caveat B)
@@ -638,13 +632,8 @@ class OptimNetwork(nn.Module):
 
         # --- deformation regulariser (network.py:565-582)
         if use_regu:
-            if use_regu_split:
-                defB = self._def_regu_mean(torch.cat([initTmpPs, initTmpPs + nl2[:nr] * 0.01], dim=0), d_cond, N, ratio)
-                nA, nB = regu_idx.shape[0], nr
-                def_loss = defA * (float(nA) / float(nA + nB)) + defB * (float(nB) / float(nA + nB))
-            else:
-                pts = torch.cat([initTmpPs, self.TmpVs.detach()[regu_idx]], dim=0)
-                def_loss = self._def_regu_mean(torch.cat([pts, pts + nl2 * 0.01], dim=0), d_cond, N, ratio)
+            pts = torch.cat([initTmpPs, self.TmpVs.detach()[regu_idx]], dim=0)
+            def_loss = self._def_regu_mean(torch.cat([pts, pts + nl2 * 0.01], dim=0), d_cond, N, ratio)
             self.info['def_loss'] = def_loss.detach()
             wpool = srdist.pooled_mean_weight(n_regu, device)
             if wpool is not None:
@@ -718,6 +707,14 @@ class OptimNetwork(nn.Module):
                     extra = value
             total_loss = total_loss + extra
 
+        # guard of the eager contract (docstring (a)): remember one gradient tensor the inner backwards of this call deposited
+        self._eager_guard = None
+        if torch.is_grad_enabled() and (EAGER_TEMPLATE_TERM or EAGER_RAY_BRANCH):
+            lw = getattr(self.dataset, 'learnable_weights', None)
+            for leaf in (lw() if lw is not None else ()):
+                if leaf.grad is not None:
+                    self._eager_guard = (leaf, leaf.grad)
+                    break
         self.remesh_time = np.floor(self.remesh_time) + float(self.forward_time % self.remesh_intersect) / float(self.remesh_intersect)
         self.info['remesh'] = self.remesh_time
         self.forward_time += 1
@@ -902,7 +899,14 @@ class OptimNetwork(nn.Module):
         """After loss.backward(): push d loss / d TmpPs into the SDF, deformer, per-frame codes / poses / trans
         through the constraint system f(p) = 0, [v]x (d(p) - c) = 0 (network.py:702-814).
         `overlap` (extension): a dist.GradBucket whose early group (gradients this pass does not touch) is all-reduced
-        asynchronously while the pass runs."""
+        asynchronously while the pass runs.
+        Must follow forward() and loss.backward() of the SAME iteration with no zero_grad() in between (forward()'s docstring: the eager
+        schedule has deposited gradients inside forward(); raises if they are gone)."""
+        guard, self._eager_guard = getattr(self, '_eager_guard', None), None
+        if guard is not None and guard[0].grad is not guard[1]:
+            raise RuntimeError("propagateTmpPsGrad: the gradients forward() deposited (mask / template / colour / normal terms are back-propagated "
+                               "inside forward() in the eager schedule) were discarded before the optimizer step -- call zero_grad() BEFORE "
+                               "forward(), or set SR_EAGER_TEMPLATE_TERM=0 SR_EAGER_RAY_BRANCH=0 for one backward of the total loss")
         if overlap is not None and srdist.is_distributed():
             self._finish_ray_branch(final=False)                      # (the render codes' gradient, if the colour term reaches them)
             mlp_engine.flush_param_grads(only=overlap.early_ids)      # their deferred weight gradients are final: materialise them now

@@ -6,8 +6,7 @@ ImplicitNetwork + CompositeDeformer([MLPTranslator, LBSkinner]) it runs the devi
 (`_optimize_device_driven`): the queue of unfinished rays is compacted on the GPU after every step and
 every row count stays in device memory; per Newton step the host issues a fixed sequence -- first-layer
 inputs of both networks, a chain over all forward layers of the sdf-only SDF MLP and the deformation MLP
-side by side (one launch per layer pair on the device-side row count; `SR_CHAIN_PERSISTENT=1`: ONE
-persistent launch with device-wide barriers), LBS + Jacobian + convergence test + residual cotangents, the
+side by side (one launch per layer pair on the device-side row count), LBS + Jacobian + convergence test + residual cotangents, the
 chain over all reverse layers, Newton update + retirement + compaction -- with no autograd graph, no
 per-frame Python loop and no host synchronisation.  The convergence test of step k and the gradient
 of step k+1 come from the same evaluation (the reference evaluates the same points twice).
@@ -160,11 +159,7 @@ def _newton(ev, x, bi, rays, cam, group, dthr, athr, w1, w2, update):
 # (csrc/refiner.hip + the layer chains of csrc/mlp_gemm.hip); the host issues a FIXED sequence of launches per call
 # (3 small kernels + 2 chains per Newton step) and never synchronises.
 DEVICE_DRIVEN = True
-CHAIN_PERSISTENT = os.environ.get("SR_CHAIN_PERSISTENT", "0") == "1"   # whole chain in one launch behind device-wide barriers
-                                                                                   # (56 launches per call instead of ~230, but slower: see DESIGN.md)
-CHAIN_POLL_MODE = int(os.environ.get("SR_CHAIN_POLL", "0"))     # tuning switch of the chain kernel's device-wide barrier
 _WORKSPACES = {}     # (device, stream handle) -> _RefinerWorkspace (grow-only)
-_ERROR_WATCH = {}    # device -> (pinned int32, event) of the previous call's barrier-failure flag
 
 
 class _RefinerWorkspace:
@@ -177,7 +172,6 @@ class _RefinerWorkspace:
             i = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
         self.cap, self.times_cap = cap, times_cap
         self.live = torch.zeros(times_cap + 3, dtype=torch.int32, device=dev)
-        self.sync = torch.zeros(4, dtype=torch.int32, device=dev)            # [0] chain barrier counter, [1] barrier-failure flag
         self.x, self.v = [f(cap, 3), f(cap, 3)], [f(cap, 3), f(cap, 3)]
         self.frame, self.orig = [i(cap), i(cap)], [i(cap), i(cap)]
         self.unit, self.t, self.s = f(cap, 4), f(cap, 4), f(cap)
@@ -189,7 +183,6 @@ class _RefinerWorkspace:
         self.sdf_zbar = [None] + [f(cap, me.pad4(L.K)) for L in sl[1:]]       # cotangent of layer l's INPUT (own buffer per layer:
         self.def_zbar = [None] + [f(cap, me.pad4(L.K)) for L in dl[1:]]       # the skip part of one of them is read at the end)
         self.a0bar, self.a0dbar = f(cap, me.pad4(ev.sdf_spec.K0)), f(cap, me.pad4(ev.tr.spec.K0))
-        self.pinned_err = torch.zeros(1, dtype=torch.int32).pin_memory()
 
 
 def _fill_gemm(g, A, B, C, N, K, bias, act, mode, out_scale=1.0, aux=None, naux_fwd=0, nact_bwd=0, aux_scale=1.0):
@@ -245,11 +238,6 @@ def _reverse_chain(ws, ev):
 def _optimize_device_driven(ev, cam, rays, initTmpPs, batch_inds, dthreshold, athreshold, w1, w2, times):
     dev = initTmpPs.device
     P = initTmpPs.shape[0]
-    watch = _ERROR_WATCH.pop(dev, None)
-    if watch is not None:
-        watch[1].synchronize()
-        if int(watch[0][0]) != 0:
-            raise _lib.SrError("sr_mlp_chain: the device-wide barrier of the previous refiner call gave up (persistent grid not resident)")
     # ONE grow-only workspace per (device, stream): capacity = the largest ray count seen + 1/8 headroom, in steps of 1024 rows (the
     # Bernoulli ray selection changes P every call by a few per cent; 57 KB per row, so a power-of-two rounding of 6145 rays would
     # hold 0.47 GB).  It is allocated and only ever used with its stream current, so the caching allocator may hand a replaced
@@ -295,8 +283,7 @@ def _optimize_device_driven(ev, cam, rays, initTmpPs, batch_inds, dthreshold, at
     a.p_out, a.conv_out = _lib.ptr(p_out), _lib.ptr(conv_out)
     fwd, rev = _forward_chain(ws, ev), _reverse_chain(ws, ev)
     for c in (fwd, rev):
-        c.m_mul, c.barrier, c.error, c.poll_mode = 1, ws.sync.data_ptr(), ws.sync.data_ptr() + 4, CHAIN_POLL_MODE
-        c.m_cap, c.persistent = P, 1 if CHAIN_PERSISTENT else 0
+        c.m_mul, c.m_cap = 1, P
     with _lib.on_device(dev):
         st = _lib.stream_of(x0)
         ra = ctypes.byref(a)
@@ -331,9 +318,6 @@ def _optimize_device_driven(ev, cam, rays, initTmpPs, batch_inds, dthreshold, at
         _lib.call("sr_refine_mid", ra, times + 1, 2, st)
         if prof is not None:
             prof.chains.append((marks, ws.live[:times + 2].clone(), me.PROFILE.overlap))
-        ws.pinned_err.copy_(ws.sync[1:2], non_blocking=True)
-        e = torch.cuda.Event(); e.record()
-        _ERROR_WATCH[dev] = (ws.pinned_err, e)
     x0.record_stream(torch.cuda.current_stream(dev)); bi.record_stream(torch.cuda.current_stream(dev))
     initTmpPs.copy_(p_out)
     return initTmpPs.detach(), conv_out.bool(), ws

@@ -1,4 +1,4 @@
-"""The device-driven refiner (csrc/refiner.hip + the persistent layer chains): (1) a chain launch equals the layer-by-layer
+"""The device-driven refiner (csrc/refiner.hip + the layer chains of csrc/mlp_gemm.hip): (1) a chain launch equals the layer-by-layer
 launches bit for bit, on a row count read from device memory; (2) the compacting refiner returns the same points / flags as the
 layer-by-layer host loop on a batch where rays finish at every step, leave no ray behind, and is deterministic;
 (3) launch count per call = 3 + 5*times + 3 (+1 init)."""
@@ -53,20 +53,17 @@ def test_chain_equals_layerwise_launches_on_a_device_row_count():
         ws.a0[:P].copy_(A0); ws.a0d[:P].copy_(A0d)
         ws.live[0] = M
         fwd = F._forward_chain(ws, ev)
-        fwd.m_mul, fwd.barrier, fwd.error, fwd.m_dev, fwd.m_cap = 1, ws.sync.data_ptr(), ws.sync.data_ptr() + 4, ws.live.data_ptr(), 3072
-        for persistent in (0, 1):                            # per-layer launches and the one-launch form with device-wide barriers
-            fwd.persistent = persistent
-            for t in ws.sdf_act + ws.def_act:
-                t.fill_(float('nan'))
-            _lib.call("sr_mlp_chain", ctypes.byref(fwd), _lib.stream_of(x))
-            torch.cuda.synchronize()
-            assert int(ws.sync[1]) == 0                      # the device-wide barrier never gave up
-            for a, b, L in zip(ws.sdf_act, ref_s, ev.sdf_spec.layers):
-                n = L.N + L.nfill                            # (the pad columns of a row are never written by either path)
-                assert torch.equal(a[:M, :n], b[:, :n])      # bit-identical: same tile code, same k order
-                assert torch.isnan(a[M:]).all()              # rows past the live count untouched
-            for a, b, L in zip(ws.def_act, ref_d, ev.tr.spec.layers):
-                assert torch.equal(a[:M, :L.N], b[:, :L.N])
+        fwd.m_mul, fwd.m_dev, fwd.m_cap = 1, ws.live.data_ptr(), 3072
+        for t in ws.sdf_act + ws.def_act:
+            t.fill_(float('nan'))
+        _lib.call("sr_mlp_chain", ctypes.byref(fwd), _lib.stream_of(x))
+        torch.cuda.synchronize()
+        for a, b, L in zip(ws.sdf_act, ref_s, ev.sdf_spec.layers):
+            n = L.N + L.nfill                            # (the pad columns of a row are never written by either path)
+            assert torch.equal(a[:M, :n], b[:, :n])      # bit-identical: same tile code, same k order
+            assert torch.isnan(a[M:]).all()              # rows past the live count untouched
+        for a, b, L in zip(ws.def_act, ref_d, ev.tr.spec.layers):
+            assert torch.equal(a[:M, :L.N], b[:, :L.N])
         # reverse chain == me.reverse (input gradients)
         ones = ev.unit_cotangent(M)
         tcot = fx.det_tensor((M, 4), 10, 1.0).to(DEV); tcot[:, 3] = 0
@@ -74,10 +71,9 @@ def test_chain_equals_layerwise_launches_on_a_device_row_count():
         rd, _, _ = me.reverse(ev.tr.spec, A0d[:M].contiguous(), ev.def_WT, ref_d, tcot, 1, True, False)
         ws.unit[:M].copy_(ones); ws.t[:M].copy_(tcot)
         rev = F._reverse_chain(ws, ev)
-        rev.m_mul, rev.barrier, rev.error, rev.m_dev, rev.m_cap, rev.persistent = 1, ws.sync.data_ptr(), ws.sync.data_ptr() + 4, ws.live.data_ptr(), 3072, 0
+        rev.m_mul, rev.m_dev, rev.m_cap = 1, ws.live.data_ptr(), 3072
         _lib.call("sr_mlp_chain", ctypes.byref(rev), _lib.stream_of(x))
         torch.cuda.synchronize()
-        assert int(ws.sync[1]) == 0
         skip = ws.sdf_zbar[4][:M, 473:512]
         got = ws.a0bar[:M, :39] + skip
         assert torch.equal(got, rs[:, :39]) and torch.equal(ws.a0dbar[:M, :167], rd[:, :167])

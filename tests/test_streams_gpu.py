@@ -7,9 +7,12 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_polling_nonzero_equals_torch_nonzero(monkeypatch):
+def test_traced_nonzero_equals_torch_nonzero(monkeypatch):
+    """The traced form of the iteration's round trips (tools/host_profile.py: count copy + event polling + nonzero_static) returns what
+    torch's nonzero returns."""
     from selfreconcode_amd import hostsync
-    monkeypatch.setattr(hostsync, 'POLL', True)
+    seen = []
+    monkeypatch.setattr(hostsync, 'TRACE', seen.append)
     g = torch.Generator(device=DEV); g.manual_seed(3)
     for shape in [(0,), (1,), (4097,), (3, 37, 41), (2, 5, 0)]:
         m = torch.rand(shape, device=DEV, generator=g) < 0.3
@@ -26,6 +29,9 @@ def test_polling_nonzero_equals_torch_nonzero(monkeypatch):
         idx = hostsync.nonzero(m).view(-1)
     torch.cuda.current_stream().wait_stream(side)
     assert torch.equal(idx, m.nonzero().view(-1))
+    assert 'count copy issued' in seen and 'count on the host' in seen
+    lists, (extra,) = hostsync.nonzero_many([m, ~m], also=[m.sum()])
+    assert torch.equal(lists[0], m.nonzero().view(-1)) and torch.equal(lists[1], (~m).nonzero().view(-1)) and extra == int(m.sum())
 
 
 def test_device_flag_orders_a_side_stream_behind_the_main_stream():
