@@ -140,6 +140,7 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
 
     conv = []
     state = {"it": 0}
+    coll = {"on": False, "events": []}      # (N > 1 or forced collectives) event pairs around the gradient all-reduce of the timed steps
 
     def step():
         it = state["it"]
@@ -148,7 +149,14 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
         loss = net(ds.batch(f), RAYS, ratio_of(it), f)
         loss.backward()
         net.propagateTmpPsGrad(f, ratio_of(it), overlap=bucket)
-        bucket.all_reduce_mean()
+        if coll["on"]:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            bucket.all_reduce_mean()
+            e1.record()
+            coll["events"].append((e0, e1))
+        else:
+            bucket.all_reduce_mean()
         opt.step()
         conv.append(net.info['rayInfo'])
         state["it"] = it + 1
@@ -165,6 +173,8 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
         the end of the window (GPU loaded), and how long the final synchronisation waits after the host has issued the last step
         (~0: the host is the bottleneck; several ms: the GPU is, the host runs ahead)."""
         conv.clear()
+        coll["events"].clear()
+        coll["on"] = sense and srdist.is_distributed()
         barrier()
         t0 = time.perf_counter()
         for i in range(n):
@@ -179,7 +189,20 @@ def run_stage(stage, args, rank, world, device, steps, warmup, settle, settle_lo
         if sense:
             diag["host_issue_ms_per_step"] = round((t_issued - t0) / n * 1e3, 3)
             diag["host_ahead_ms_at_the_end"] = round((t0 + el - t_issued) * 1e3, 3)
+        coll["on"] = False
         t = torch.tensor([el], device=device, dtype=torch.float64)
+        if sense and srdist.is_distributed():
+            # a multi-rank record explains itself: every rank's own step time (the headline is their maximum), and the time the main
+            # stream spends in the gradient all-reduce section (flat gather + all-reduce + scatter of both buckets; the early bucket
+            # has been running under the implicit-gradient pass) per step on every rank
+            ar = sum(a.elapsed_time(b) for a, b in coll["events"]) / max(len(coll["events"]), 1)
+            mine = torch.tensor([el / n * 1e3, ar], device=device, dtype=torch.float64)
+            allr = [torch.zeros_like(mine) for _ in range(torch.distributed.get_world_size())]
+            torch.distributed.all_gather(allr, mine)
+            per = [round(float(x[0]), 3) for x in allr]
+            diag["per_rank_ms_per_step"] = per
+            diag["straggler_ms"] = round(max(per) - min(per), 3)
+            diag["grad_allreduce_section_ms_per_step_by_rank"] = [round(float(x[1]), 3) for x in allr]
         if srdist.is_distributed():
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         tot = sum(int(r[0]) for r in conv); cv = sum(int(r[1]) for r in conv)
@@ -454,19 +477,40 @@ def main():
         srdist.simulate_world((0, 8))
         try:
             rs = strip(run_stage("coarse", args, rank, world, device, short["steps"], short["warmup"], short["settle"], 0, False, frames=1))
+            # the same rank's step with every collective LIVE through RCCL at world size 1 (both gradient buckets, the template-vertex
+            # all-reduce, the pooled-mean weights, the count guards): what they cost in launches, copies and host time; the wire time of
+            # the 8-GPU group is added analytically below
+            srdist.force_collectives(True, device)
+            try:
+                rc = strip(run_stage("coarse", args, rank, world, device, short["steps"], short["warmup"], short["settle"], 0, False, frames=1))
+            finally:
+                srdist.force_collectives(False)
         finally:
             srdist.simulate_world(None)
         am = lambda r: r["ms_per_step_remesh_amortised"] or r["ms_per_step"]       # one remesh per 30 iterations (the 20-step window holds one: 1/20)
+        # wire time of the step's collectives on 8 GPUs, from the guide's xGMI figures (7 links x ~153 GB/s per GPU, point to point): a ring
+        # all-reduce moves 2 (N-1)/N of the buffer over each rank's slowest link; the two gradient buckets (3.8 MB early -- under the
+        # implicit-gradient pass, so not on the critical path -- and 11.4 MB main) and the template-vertex gradient (V x 3 floats)
+        wire = lambda nbytes: 2.0 * 7.0 / 8.0 * nbytes / 153e9 * 1e3 + 0.03            # ms: bandwidth term + ~30 us of latency per collective
+        wire_ms = round(wire(11.4e6) + wire(rs["template_vertices"] * 12) + 2 * 0.03, 3)   # main bucket + template all-reduce + two 4-byte weights
         strong_rec = {"workload": "configs[2]: 8 frames x 2048 rays per step (coarse stage, lr 1e-4); measured on ONE GPU; ms with the remesh amortised over its interval of 30",
                       "ms_8_frames_one_gpu": am(r8), "ms_1_frame_replicated_template_term": am(r1),
                       "ms_one_rank_of_8": am(rs),
+                      "ms_one_rank_of_8_collectives_live_world1": am(rc),
+                      "grad_allreduce_section_ms_world1": (rc["diagnostics"].get("grad_allreduce_section_ms_per_step_by_rank") or [None])[0],
+                      "modelled_wire_ms_8_gpus": wire_ms,
+                      "ms_one_rank_of_8_with_collectives": round(am(rc) + wire_ms, 3),
+                      "modelled_speedup_8_gpus_with_collectives": round(am(r8) / (am(rc) + wire_ms), 2),
                       "modelled_speedup_8_gpus": round(am(r8) / am(rs), 2),
                       "modelled_speedup_8_gpus_without_sharding": round(am(r8) / am(r1), 2),
                       "ms_in_the_20_step_window": {"8_frames": r8["ms_per_step"], "1_frame": r1["ms_per_step"], "one_rank_of_8": rs["ms_per_step"]},
                       "remesh_ms_each": rs["remesh"]["ms_each"],
                       "note": "one_rank_of_8 = 1 frame per step with mean|f(TmpVs)| evaluated on vertices 0::8 (dist.shard_world; the gradient all-reduce restores "
                               "the full mean); the remesh's SDF queries are sharded the same way on a real group (one all-gather per level) but run in full "
-                              "here; collectives (15 MB all-reduce, ~0.2 ms over xGMI) are not in the model"}
+                              "here.  `ms_one_rank_of_8_collectives_live_world1` runs the same step with every collective live through RCCL at world size 1 (launches, "
+                              "flat copies, host time: everything but the wire); `modelled_wire_ms_8_gpus` = ring all-reduce of the 11.4 MB main bucket and the "
+                              "template-vertex gradient at 2 x 7/8 x bytes / 153 GB/s + 30 us each (the 3.8 MB early bucket runs under the implicit-gradient pass); "
+                              "`ms_one_rank_of_8_with_collectives` is their sum"}
         seg_rec = seg3d_mc_513_record(device)
         from selfreconcode_amd.config import loose_config
         rl = strip(run_stage("coarse", args, rank, world, device, min(args.steps, 20), args.warmup, max(args.settle // 3, 0), 0, False,

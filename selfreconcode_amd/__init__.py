@@ -1,11 +1,12 @@
 """MI355X-native hot path of SelfRecon."""
 import os as _os
 
-if _os.environ.get("SR_AUTOGRAD_CALLER_THREAD", "1") != "0":
-    # The iteration runs nine autograd traversals, each a few hundred nodes whose backward is a handful of C-ABI launches.  With the
-    # engine's default threading every traversal is handed to the device's worker thread and the caller sleeps on a condition variable
-    # until it is done: two thread wake-ups per traversal and a GIL hand-over per Python node.  On the calling thread the same nodes
-    # run in the same order on the same streams (the engine's stream guards do not depend on the thread), without the hand-overs.
-    # Thread-local to the importing thread; SR_AUTOGRAD_CALLER_THREAD=0 leaves torch's default.
+if _os.environ.get("SR_AUTOGRAD_CALLER_THREAD", "0") == "1":
+    # Opt-in experiment (round 6): run autograd traversals on the calling thread instead of handing each of the iteration's nine
+    # traversals to the engine's device thread.  Saves 0.2 - 1.4 ms of thread hand-overs per step where the host paces the step (one
+    # frame per rank), nothing at three frames.  NOT the default: with the worker thread the first node handed over starts at once,
+    # on the calling thread all ready nodes are queued first and run in strict priority order -- a different (equally valid) order of
+    # the first accumulations of a traversal, i.e. sums that differ in the last bit, and the long free-running parity trajectories
+    # (tests/test_trajectory_full_gpu.py) are pinned to the default order.
     import torch as _torch
     _torch.autograd.set_multithreading_enabled(False)

@@ -22,6 +22,17 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte load through a buffer descriptor: `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen` -- the address is descriptor base (4
+// SGPRs, fixed per tile) + a 32-bit per-lane byte offset that never changes + a 32-bit SCALAR byte offset that advances with the step:
+// no vector arithmetic at all in front of a tile-loop load (the flat form needs a 64-bit per-lane add per load and step).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sr_make_rsrc(const void* base, int64_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes < 0xFFFFFFFFll ? bytes : 0xFFFFFFFFll), 0x00020000);
+}
+__device__ __forceinline__ f32x4 sr_buffer_load16(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane_off, uint32_t scalar_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)scalar_off, 0));
+}
 
 namespace {
 
@@ -72,11 +83,15 @@ struct Cfg {
 template <int ROWS, int NLOADS, int THREADS>
 struct TileLoader {
   const float* p[NLOADS];   // row base + kq*4 of each slot (row clamped)
+  __amdgpu_buffer_rsrc_t rsrc;   // (KTAIL = false) descriptor of the rows from the tile's first one on; off[j] = this thread's byte offset
+  uint32_t off[NLOADS];
   int kq4;                  // this thread's k offset inside a tile (same for all slots: THREADS % 8 == 0)
   int K, kmax;              // logical K and the last float4 start that stays inside the padded row
   __device__ __forceinline__ TileLoader(const float* __restrict__ P, int64_t ld, int R, int K_, int r0) : K(K_) {
     kq4 = (threadIdx.x & 7) * 4;
     kmax = ((K_ + 3) & ~3) - 4;
+    const int rb = r0 < R ? r0 : R - 1;
+    rsrc = sr_make_rsrc(P + (int64_t)rb * ld, (int64_t)(R - rb) * ld * 4);
 #pragma unroll
     for (int j = 0; j < NLOADS; ++j) {
       int row = (threadIdx.x + j * THREADS) >> 3;
@@ -84,6 +99,7 @@ struct TileLoader {
       int gr = r0 + row;
       if (gr >= R) gr = R - 1;
       p[j] = P + (int64_t)gr * ld;
+      off[j] = (uint32_t)(((int64_t)(gr - rb) * ld + kq4) * 4);      // < ROWS * ld * 4 bytes
     }
   }
   // raw loads; the K tail is masked when the registers are written to LDS (a select right after the load would make the
@@ -93,6 +109,13 @@ struct TileLoader {
     const int gkc = gk < kmax ? gk : kmax;
 #pragma unroll
     for (int j = 0; j < NLOADS; ++j) reg[j] = *reinterpret_cast<const f32x4*>(p[j] + gkc);
+  }
+  // K % 32 == 0 (no float4 reaches past K): buffer loads, the step's k offset is the scalar offset.  A prefetch past the last tile
+  // re-reads the last one.
+  __device__ __forceinline__ void load_full(int k0, int klast, f32x4 (&reg)[NLOADS]) const {
+    const uint32_t kc = (uint32_t)(k0 < klast ? k0 : klast) * 4u;
+#pragma unroll
+    for (int j = 0; j < NLOADS; ++j) reg[j] = sr_buffer_load16(rsrc, off[j], kc);
   }
   // KTAIL = false: K is a multiple of BK (every 512-wide layer), no float4 reaches past K and the four selects per slot -- 32 VALU
   // operations per thread and step, next to 64 MFMAs -- are not compiled in.
@@ -351,8 +374,13 @@ __device__ __forceinline__ void gemm_nt_tile(const sr_gemm_args& g, int wg, floa
   // stamps (profiles/r01_summary.md): with the memory operations in their own phase the wave spent 1000-1500 clk per
   // 4096-clk step with an idle MFMA pipe.
   f32x4 ra0[C_::kALoads], rb0[C_::kBLoads], ra1[C_::kALoads], rb1[C_::kBLoads];
-  la.load(0, ra0); lb.load(0, rb0);
-  la.load(BK, ra1); lb.load(BK, rb1);
+  const int klast = (nk - 1) * BK;
+  auto load_tile = [&](int k0, f32x4 (&ar)[C_::kALoads], f32x4 (&br)[C_::kBLoads]) {
+    if constexpr (KTAIL) { la.load(k0, ar); lb.load(k0, br); }
+    else { la.load_full(k0, klast, ar); lb.load_full(k0, klast, br); }
+  };
+  load_tile(0, ra0, rb0);
+  load_tile(BK, ra1, rb1);
   la.template store<KTAIL>(As(0), 0, ra0); lb.template store<KTAIL>(Bs(0), 0, rb0);
   __syncthreads();
   read_frags(As(0), Bs(0), 0, fa0, fb0);
@@ -360,7 +388,7 @@ __device__ __forceinline__ void gemm_nt_tile(const sr_gemm_args& g, int wg, floa
   auto step = [&](int t, f32x4 (&ain)[C_::kALoads], f32x4 (&bin)[C_::kBLoads], const f32x4 (&aout)[C_::kALoads],
                   const f32x4 (&bout)[C_::kBLoads]) {
     const int cur = t & 1;
-    la.load((t + 2) * BK, ain); lb.load((t + 2) * BK, bin);
+    load_tile((t + 2) * BK, ain, bin);
     la.template store<KTAIL>(As(cur ^ 1), (t + 1) * BK, aout); lb.template store<KTAIL>(Bs(cur ^ 1), (t + 1) * BK, bout);
     read_frags(As(cur), Bs(cur), 2, fa1, fb1);
     mfma_kk(fa0[0], fb0[0]);
@@ -501,9 +529,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
   // The ISA of the single form had 192 VALU operations per step next to its 64 MFMAs (16 quarter-rate v_mul_lo_u32, 32 selects, 26
   // bias adds in every workgroup although only the k0 == 0 column of tiles folds a bias gradient): the kernel ran at 118 TFLOP/s where
   // the NT tile code (12 VALU operations per step) reaches 135.
-  // (round 6) a full-tile load is `global_load_dwordx4 v, v_off, s[base]`: the tile's first row as a 64-bit SCALAR base, the thread's
-  // place inside a tile as a 32-bit byte offset that never changes -- no per-lane 64-bit add in front of every load (the step had 16 of
-  // them).  A tile spans at most TBR rows of the wider operand, far below 4 GB.
+  // (round 6) a full-tile load is a buffer load: descriptor = the slab's rows, the thread's place inside a tile a 32-bit byte offset that
+  // never changes, the tile's first row a SCALAR byte offset -- no per-lane 64-bit add in front of every load (the step had 16 of them).
+  const __amdgpu_buffer_rsrc_t zrsrc = sr_make_rsrc(g.Z + (int64_t)r_begin * g.ldz, (int64_t)(g.R - r_begin) * g.ldz * 4);
+  const __amdgpu_buffer_rsrc_t xrsrc = sr_make_rsrc(g.A + (int64_t)r_begin * g.lda, (int64_t)(g.R - r_begin) * g.lda * 4);
   uint32_t zbyte[TLZ], xbyte[TLX];
 #pragma unroll
   for (int j = 0; j < TLZ; ++j) zbyte[j] = (uint32_t)(((int64_t)(lrz + j * (256 / ZT)) * g.ldz + (zcol - g.Z)) * 4);
@@ -526,12 +555,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
       }
     } else {
       const int rc = r0 < last_full ? r0 : last_full;                       // (uniform)
-      const char* zrow = reinterpret_cast<const char*>(g.Z + (int64_t)rc * g.ldz);   // (uniform: scalar arithmetic)
-      const char* xrow = reinterpret_cast<const char*>(g.A + (int64_t)rc * g.lda);
+      const uint32_t zo = (uint32_t)((int64_t)(rc - r_begin) * g.ldz * 4), xo = (uint32_t)((int64_t)(rc - r_begin) * g.lda * 4);   // (uniform)
 #pragma unroll
-      for (int j = 0; j < TLZ; ++j) rz[j] = *reinterpret_cast<const f32x4*>(zrow + zbyte[j]);
+      for (int j = 0; j < TLZ; ++j) rz[j] = sr_buffer_load16(zrsrc, zbyte[j], zo);
 #pragma unroll
-      for (int j = 0; j < TLX; ++j) rx[j] = *reinterpret_cast<const f32x4*>(xrow + xbyte[j]);
+      for (int j = 0; j < TLX; ++j) rx[j] = sr_buffer_load16(xrsrc, xbyte[j], xo);
     }
   };
   auto store = [&](int buf, int r0, auto tail) {

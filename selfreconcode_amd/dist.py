@@ -49,6 +49,24 @@ def init_from_env(device_type="cuda", bind_cpus=False):
 _FORCED = False
 
 
+def force_collectives(on=True, device=None):
+    """Run every collective of the step through the real backend at WORLD SIZE 1 (bench.py: what the gradient buckets, the template
+    all-reduce and the small count / weight collectives cost in launches and copies when the wire time is zero).  Initialises a
+    one-rank process group on first use (backend `nccl` = RCCL on a GPU, SR_DIST_BACKEND overrides); `on=False` switches the collectives
+    off again and leaves the group alive.  No-op inside a real multi-rank group."""
+    global _FORCED
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return
+    if on and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        cuda = device is not None and torch.device(device).type == "cuda"
+        backend = os.environ.get("SR_DIST_BACKEND", "nccl" if cuda else "gloo")
+        kw = {"device_id": torch.device(device)} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, rank=0, world_size=1, **kw)
+    _FORCED = bool(on)
+
+
 def is_distributed():
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCED)
 
