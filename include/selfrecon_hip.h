@@ -158,6 +158,17 @@ typedef struct {
 } sr_gemm_tn_args;
 int64_t sr_mlp_gemm_tn_workspace_floats(int32_t R, int32_t N, int64_t lddw, int32_t* host_splits_out);
 int sr_mlp_gemm_tn(const sr_gemm_tn_args* host_args, void* stream);
+/* Up to SR_TN_GROUP_MAX independent weight gradients of the general tile shape (not the K <= 64 & N >= 256 first-layer shape) in ONE
+ * launch + one launch for their slab reductions: the reverse sweep of a network on a few thousand rows (the ray branch, the
+ * implicit-gradient pass: network.py:599-639, 702-814) leaves one weight gradient per layer, each too small to fill the machine.
+ * Every problem is computed exactly as sr_mlp_gemm_tn would compute it alone (same tiles, same slabs, same reduction order: bit-identical);
+ * no two problems of a call may share dW / db / partial. */
+#define SR_TN_GROUP_MAX 12
+typedef struct {
+  int32_t n;
+  sr_gemm_tn_args p[SR_TN_GROUP_MAX];
+} sr_gemm_tn_group_args;
+int sr_mlp_gemm_tn_group(const sr_gemm_tn_group_args* host_args, void* stream);
 /* Bias gradient: out[n] += sum_{r % group == 0} Z[r][n]  (out must be zero-filled or hold the running sum). */
 int sr_colsum_rows(const float* Z, int64_t ldz, int32_t R, int32_t N, int32_t group, float* out, void* stream);
 

@@ -31,6 +31,13 @@ class SrGemmTnArgs(ctypes.Structure):
                 ("accumulate", ctypes.c_int32), ("db", _vp), ("db_partial", _vp), ("group", ctypes.c_int32)]
 
 
+SR_TN_GROUP_MAX = 12
+
+
+class SrGemmTnGroupArgs(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("p", SrGemmTnArgs * SR_TN_GROUP_MAX)]
+
+
 class SrLbsArgs(ctypes.Structure):
     _fields_ = [("p", _vp), ("tp", _vp), ("P", _i64), ("A", _vp), ("trans", _vp), ("nframes", ctypes.c_int32),
                 ("batch_inds", _vp), ("points_per_frame", _i64), ("vol", _vp), ("D", ctypes.c_int32), ("H", ctypes.c_int32),
@@ -160,6 +167,7 @@ SIGNATURES = {
     "sr_refine_finish": [_vp, ctypes.c_int32, _vp],
     "sr_mlp_gemm_tn_workspace_floats": [ctypes.c_int32, ctypes.c_int32, _i64, _vp],
     "sr_mlp_gemm_tn": [_vp, _vp],
+    "sr_mlp_gemm_tn_group": [_vp, _vp],
     "sr_colsum_rows": [_vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
     "sr_lbs_chain_fwd": [_vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp],
     "sr_lbs_chain_bwd": [_vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -481,10 +481,11 @@ struct TnCfg {
   static constexpr int WN = XW / 64;                                      // waves along the A columns
 };
 
+// One workgroup of a weight-gradient launch: tile and row slab from (`bid`, `nblocks`) -- the workgroup's index and the workgroup count of
+// ITS problem, which is the whole grid for gemm_tn_kernel and a slice of it for gemm_tn_group_kernel.
 template <int ZW, int XW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_tn_kernel(sr_gemm_tn_args g, int rows_per_split) {
+__device__ __forceinline__ void gemm_tn_body(const sr_gemm_tn_args& g, int rows_per_split, int bid, int nblocks, float* __restrict__ tn_smem) {
   using C = TnCfg<ZW, XW>;
-  extern __shared__ __attribute__((aligned(16))) float tn_smem[];
   auto Zs = [&](int buf) -> float* { return tn_smem + buf * C::kZ; };
   auto Xs = [&](int buf) -> float* { return tn_smem + 2 * C::kZ + buf * C::kX; };
   const int tiles_k = (g.K + XW - 1) / XW;
@@ -492,8 +493,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
   // XCD-aware order: workgroup b runs on XCD b % 8 with a private L2.  The tiles of one row-slice (split) all read the
   // same Z and A rows, so give each XCD whole splits: virtual id = xcd * (grid/8) + b / 8.  (Before: the 4 k-tiles /
   // 4 n-tiles of a slice sat on different XCDs and every operand row was streamed from HBM 4 times.)
-  int vb = blockIdx.x;
-  if ((gridDim.x & 7) == 0) vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  int vb = bid;
+  if ((nblocks & 7) == 0) vb = (bid & 7) * (nblocks >> 3) + (bid >> 3);
   const int tile = vb % (tiles_k * tiles_n), split = vb / (tiles_k * tiles_n);
   const int n0 = (tile / tiles_k) * ZW, k0 = (tile % tiles_k) * XW;
   const int r_begin = split * rows_per_split;
@@ -703,6 +704,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
 }
 
+template <int ZW, int XW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_tn_kernel(sr_gemm_tn_args g, int rows_per_split) {
+  extern __shared__ __attribute__((aligned(16))) float tn_smem[];
+  gemm_tn_body<ZW, XW>(g, rows_per_split, blockIdx.x, gridDim.x, tn_smem);
+}
+
+// Several independent weight gradients of the 128 x 128 tile shape in ONE launch (sr_mlp_gemm_tn_group): the small reverse sweeps of the
+// ray branch and the implicit-gradient pass (1-5k rows) produce one weight gradient per layer, each a launch of < 100 workgroups that
+// ends before the next has started -- 26 launches per iteration at 27 TFLOP/s.  Here the workgroups of all of them share a grid
+// (`first[i]` = first workgroup of problem i, a multiple of 8 so that the XCD-aware tile order of the body still sees block b on XCD
+// b % 8); every workgroup runs the same tile body on the same slab as the single launch would: bit-identical partials.
+struct TnGroup {
+  int n;
+  int first[SR_TN_GROUP_MAX + 1];
+  int blocks[SR_TN_GROUP_MAX];            // workgroups problem i really has (first[i + 1] - first[i] rounded it up to a multiple of 8)
+  int rows_per_split[SR_TN_GROUP_MAX];
+  sr_gemm_tn_args p[SR_TN_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_tn_group_kernel(TnGroup G) {
+  extern __shared__ __attribute__((aligned(16))) float tn_smem[];
+  int i = 0;
+  while (i + 1 < G.n && (int)blockIdx.x >= G.first[i + 1]) ++i;      // (uniform)
+  const int bid = blockIdx.x - G.first[i];
+  if (bid >= G.blocks[i]) return;
+  gemm_tn_body<128, 128>(G.p[i], G.rows_per_split[i], bid, G.blocks[i], tn_smem);
+}
+
 // 256 x 64 tiles when the A operand is at most 64 columns wide and dW has at least 256 rows
 static inline bool tn_narrow(int N, int64_t K) { return K <= 64 && N >= 256; }
 
@@ -712,15 +740,15 @@ static inline bool tn_narrow(int N, int64_t K) { return K <= 64 && N >= 256; }
 // issued before the first of them is added -- the plain loop (`s += partial[p * total + i]`, trip count unknown to the compiler) waited
 // for every slab's load in turn: 22 us for 16-32 slabs of a 512 x 512 gradient, i.e. memory latency x slabs, ninety times per iteration
 // on the weight-gradient stream.  Same order of additions per element, same bits.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int N,
-                                                           int K, int64_t lddw, int splits, int accumulate,
-                                                           const float* __restrict__ db_partial, float* __restrict__ db) {
+__device__ __forceinline__ void slab_reduce_body(const float* __restrict__ partial, float* __restrict__ dW, int N,
+                                                 int K, int64_t lddw, int splits, int accumulate,
+                                                 const float* __restrict__ db_partial, float* __restrict__ db, int bid, int nblocks) {
   const int64_t total = (int64_t)N * lddw;
   const int64_t quads = total >> 2;                      // lddw % 4 == 0 (checked by the caller)
   const int64_t all = quads + (db ? N : 0);
   const f32x4* __restrict__ p4 = reinterpret_cast<const f32x4*>(partial);
   f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(dW);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < all; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < all; i += (int64_t)nblocks * blockDim.x) {
     if (i < quads) {
       const int col = (int)((i << 2) % lddw);
       f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -749,6 +777,22 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
       db[n] = (accumulate ? db[n] : 0.f) + s;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int N,
+                                                           int K, int64_t lddw, int splits, int accumulate,
+                                                           const float* __restrict__ db_partial, float* __restrict__ db) {
+  slab_reduce_body(partial, dW, N, K, lddw, splits, accumulate, db_partial, db, blockIdx.x, gridDim.x);
+}
+
+// the slab reductions of a grouped weight-gradient launch, one launch too (same element order as the single reductions)
+__global__ __launch_bounds__(256) void slab_reduce_group_kernel(TnGroup G) {
+  int i = 0;
+  while (i + 1 < G.n && (int)blockIdx.x >= G.first[i + 1]) ++i;
+  const int bid = blockIdx.x - G.first[i];
+  if (bid >= G.blocks[i]) return;
+  const sr_gemm_tn_args& g = G.p[i];
+  slab_reduce_body(g.partial, g.dW, g.N, g.K, g.lddw, g.R > 0 ? g.splits : 0, g.accumulate, g.db_partial, g.db, bid, G.blocks[i]);
 }
 
 // out[n] = sum over primal rows (r % group == 0) of Z[r][n]; one workgroup per 64 columns x row-slice,
@@ -907,6 +951,46 @@ int sr_mlp_gemm_tn(const sr_gemm_tn_args* a, void* stream) {
   const int64_t total = (int64_t)a->N * a->lddw / 4 + (a->db ? a->N : 0);
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(sr_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, a->partial, a->dW,
                      a->N, a->K, a->lddw, a->R > 0 ? a->splits : 0, a->accumulate, a->db_partial, a->db);
+  return sr_launch_status();
+}
+
+static int tn_check(const sr_gemm_tn_args* a) {
+  if (!a || !a->dW || !a->partial || a->R < 0 || a->N <= 0 || a->K <= 0 || a->splits < 1) return SR_EINVAL;
+  if (a->R > 0 && (!a->Z || !a->A)) return SR_EINVAL;
+  if ((a->ldz & 3) || (a->lda & 3) || ((uintptr_t)a->Z & 15) || ((uintptr_t)a->A & 15) || a->lddw < a->K) return SR_EINVAL;
+  if ((a->lddw & 3) || ((uintptr_t)a->dW & 15) || ((uintptr_t)a->partial & 15)) return SR_EINVAL;
+  if ((a->db != nullptr) != (a->db_partial != nullptr) || (a->db && a->group < 1)) return SR_EINVAL;
+  return SR_OK;
+}
+
+int sr_mlp_gemm_tn_group(const sr_gemm_tn_group_args* a, void* stream) {
+  if (!a || a->n < 1 || a->n > SR_TN_GROUP_MAX) return SR_EINVAL;
+  TnGroup G, Rd;
+  G.n = Rd.n = a->n;
+  int nb = 0, nr = 0;
+  bool any_rows = false;
+  for (int i = 0; i < a->n; ++i) {
+    const sr_gemm_tn_args& p = a->p[i];
+    const int rc = tn_check(&p);
+    if (rc != SR_OK) return rc;
+    if (tn_narrow(p.N, p.lddw)) return SR_EINVAL;            // (the 256 x 64 shape has its own LDS footprint: single launches)
+    const int tiles = (int)(sr_cdiv(p.N, 128) * sr_cdiv(p.K, 128));
+    int rows_per_split = (int)sr_cdiv(p.R, p.splits);
+    rows_per_split = (int)(sr_cdiv(rows_per_split, TBR) * TBR);
+    G.p[i] = Rd.p[i] = p;
+    G.rows_per_split[i] = Rd.rows_per_split[i] = rows_per_split;
+    G.first[i] = nb; G.blocks[i] = p.R > 0 ? tiles * p.splits : 0;
+    nb += (int)(sr_cdiv(G.blocks[i], 8) * 8);
+    const int64_t total = (int64_t)p.N * p.lddw / 4 + (p.db ? p.N : 0);
+    Rd.first[i] = nr; Rd.blocks[i] = sr_stream_grid(total, 256);
+    nr += Rd.blocks[i];
+    any_rows = any_rows || p.R > 0;
+  }
+  G.first[a->n] = nb; Rd.first[a->n] = nr;
+  using Square = TnCfg<128, 128>;
+  if (any_rows && nb > 0)
+    hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(nb), dim3(256), Square::kLdsFloats * sizeof(float), (hipStream_t)stream, G);
+  hipLaunchKernelGGL(slab_reduce_group_kernel, dim3(nr), dim3(256), 0, (hipStream_t)stream, Rd);
   return sr_launch_status();
 }
 

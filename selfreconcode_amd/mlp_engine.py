@@ -190,6 +190,33 @@ def _gemm_tn(Z, ldz, A, lda, R, N, K, lddw, group=1, dW=None, db=None, accumulat
     return dW, db
 
 
+GROUP_TN_BELOW = 16384     # rows: the weight gradients of a reverse sweep on fewer rows than this go out as ONE grouped launch (0 = never)
+
+
+def _tn_is_narrow(N, lddw):
+    return lddw <= 64 and N >= 256          # (csrc/mlp_gemm.hip::tn_narrow: the 256 x 64 tile shape of the first layers is not grouped)
+
+
+def _gemm_tn_group(problems):
+    """`problems`: list of (Z, ldz, A, lda, R, N, K, lddw, group, dW, db, accumulate) with distinct dW / db -- the weight gradients of
+    one reverse sweep.  One launch for all tiles and slabs + one for all slab reductions (sr_mlp_gemm_tn_group); each problem is computed
+    exactly as `_gemm_tn` would compute it alone: same splits, same slab order, bit-identical results."""
+    g = _lib.SrGemmTnGroupArgs()
+    g.n = len(problems)
+    sizes, total = [], 0
+    for (Z, ldz, A, lda, R, N, K, lddw, group, dW, db, accumulate) in problems:
+        splits = ctypes.c_int32(0)
+        ws = max(int(_lib.raw("sr_mlp_gemm_tn_workspace_floats")(R, N, lddw, ctypes.byref(splits))), 1)
+        sizes.append((ws, splits.value, total))
+        total += (ws + splits.value * N + 3) // 4 * 4                     # (every problem's partial block stays 16-byte aligned)
+    partial = torch.empty((total,), dtype=torch.float32, device=problems[0][0].device)
+    for a, (Z, ldz, A, lda, R, N, K, lddw, group, dW, db, accumulate), (ws, splits, off) in zip(g.p, problems, sizes):
+        a.Z, a.ldz, a.A, a.lda, a.dW, a.lddw, a.partial = _lib.ptr(Z), ldz, _lib.ptr(A), lda, _lib.ptr(dW), lddw, _lib.ptr(partial) + 4 * off
+        a.R, a.N, a.K, a.splits, a.accumulate = R, N, K, splits, 1 if accumulate else 0
+        a.db, a.db_partial, a.group = _lib.ptr(db), _lib.ptr(partial) + 4 * (off + ws), group
+    _lib.call("sr_mlp_gemm_tn_group", ctypes.byref(g), _lib.stream_of(partial))
+
+
 def _colsum(Z, ldz, R, N, group):
     out = torch.zeros((N,), dtype=torch.float32, device=Z.device)
     _lib.call("sr_colsum_rows", _lib.ptr(Z), ldz, R, N, group, _lib.ptr(out), _lib.stream_of(Z))
@@ -292,6 +319,9 @@ def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_g
     Zbar = Ybar
     A0bar = None
     seg = _bias_segments(bs[0], R, group) if bs is not None else None
+    # weight gradients of a SMALL sweep (deferred mode, their own stream): collected here and launched as one group after the last layer --
+    # each is < 100 workgroups that end before the next starts (26 launches per iteration at 27 TFLOP/s in round 5)
+    grouped = [] if (0 < R < GROUP_TN_BELOW and TN_SIDE_STREAM and not PROFILE.enabled and not DEBUG_TN_DELAY_MS) else None
     with _lib.on_device(A0.device):
         for l in range(nl - 1, -1, -1):
             L = spec.layers[l]
@@ -303,7 +333,9 @@ def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_g
                     if e is not None and any(r() is not None and r().requires_grad for r in e.get("src", ())):
                         raise RuntimeError("mlp_engine: a packed weight handed out without autograd node (deferred mode) met a layer call "
                                            "that has no deferred sink (bias that is not the layer's own leaf parameter?): its gradient would be lost")
-                if sink is not None and TN_SIDE_STREAM and not PROFILE.enabled:
+                if sink is not None and grouped is not None and not _tn_is_narrow(L.N, pad4(L.K)) and len(grouped) < _lib.SR_TN_GROUP_MAX:
+                    grouped.append((Zbar, Zbar.stride(0), X, X.stride(0), R, L.N, L.K, pad4(L.K), group, sink[0], sink[1], sink[2]))
+                elif sink is not None and TN_SIDE_STREAM and not PROFILE.enabled:
                     main, side = torch.cuda.current_stream(A0.device), _tn_stream(A0.device)
                     ready = torch.cuda.Event()
                     ready.record(main)                                   # Zbar (and, for a partial first use, the zeroed buffers) are final here
@@ -342,6 +374,20 @@ def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_g
                          EPI_FWD)
                 if A0bar_extra is not None:
                     A0bar[:, :A0bar_extra.shape[1]] += A0bar_extra
+        if grouped:
+            main, side = torch.cuda.current_stream(A0.device), _tn_stream(A0.device)
+            ready = torch.cuda.Event()
+            ready.record(main)                                           # every Zbar of the sweep is final here
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                if len(grouped) == 1:
+                    p = grouped[0]
+                    _gemm_tn(*p[:9], dW=p[9], db=p[10], accumulate=p[11])
+                else:
+                    _gemm_tn_group(grouped)
+            for p in grouped:
+                p[0].record_stream(side); p[2].record_stream(side)
+            _TN_PENDING.add(str(A0.device))
     return A0bar, dWs, dbs
 
 

@@ -62,7 +62,7 @@ def test_ctypes_structs_have_the_size_the_header_declares(tmp_path):
     (gcc compiles the header as plain C -- it has to stay a C header -- and prints sizeof for each)."""
     import subprocess
     from selfreconcode_amd import _lib
-    pairs = {"sr_tensor5": _lib.SrTensor5, "sr_gemm_args": _lib.SrGemmArgs, "sr_gemm_tn_args": _lib.SrGemmTnArgs, "sr_lbs_args": _lib.SrLbsArgs,
+    pairs = {"sr_tensor5": _lib.SrTensor5, "sr_gemm_args": _lib.SrGemmArgs, "sr_gemm_tn_args": _lib.SrGemmTnArgs, "sr_gemm_tn_group_args": _lib.SrGemmTnGroupArgs, "sr_lbs_args": _lib.SrLbsArgs,
              "sr_newton_args": _lib.SrNewtonArgs, "sr_newton2_args": _lib.SrNewton2Args, "sr_chain_args": _lib.SrChainArgs,
              "sr_refine_args": _lib.SrRefineArgs, "sr_pack_layer": _lib.SrPackLayer, "sr_pack_table": _lib.SrPackTable,
              "sr_unpack_layer": _lib.SrUnpackLayer, "sr_unpack_table": _lib.SrUnpackTable, "sr_camera": _lib.SrCamera,

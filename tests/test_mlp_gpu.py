@@ -367,6 +367,35 @@ def test_weight_gradient_stream_gives_bitwise_the_same_gradients():
         assert torch.equal(a, b)
 
 
+def test_grouped_weight_gradients_equal_the_single_launches_bit_for_bit():
+    """sr_mlp_gemm_tn_group (the weight gradients of one small reverse sweep in ONE launch + one slab-reduction launch) against one
+    sr_mlp_gemm_tn per problem: ragged row counts and widths (K = 167, 473, 289 ..., N = 3 and 257), accumulate on and off, bias gradients
+    with group 1 / 2 / 4, twelve problems at once."""
+    from selfreconcode_amd import mlp_engine as me
+    shapes = [(3000, 512, 512, 1, False), (3000, 512, 167, 1, True), (1777, 473, 512, 2, False), (4, 3, 512, 1, True), (6144, 257, 512, 4, False),
+              (129, 512, 289, 1, True), (8188, 512, 512, 4, True), (33, 512, 512, 1, False), (2048, 512, 473, 2, True), (5000, 3, 512, 1, False),
+              (1024, 512, 512, 1, True), (900, 257, 512, 1, True)]
+    single, grouped, probs = [], [], []
+    for i, (R, N, K, group, acc) in enumerate(shapes):
+        R -= R % group
+        Z = fx.det_tensor((R, me.pad4(N)), 400 + i, 1.0).to(DEV); A = fx.det_tensor((R, me.pad4(K)), 500 + i, 1.0).to(DEV)
+        dW0 = fx.det_tensor((N, me.pad4(K)), 600 + i, 1.0).to(DEV); db0 = fx.det_tensor((N,), 700 + i, 1.0).to(DEV)
+        a, b = dW0.clone(), db0.clone()
+        me._gemm_tn(Z, Z.stride(0), A, A.stride(0), R, N, K, me.pad4(K), group, dW=a, db=b, accumulate=acc)
+        single.append((a, b))
+        c, d = dW0.clone(), db0.clone()
+        grouped.append((c, d))
+        probs.append((Z, Z.stride(0), A, A.stride(0), R, N, K, me.pad4(K), group, c, d, acc))
+    me._gemm_tn_group(probs)
+    torch.cuda.synchronize()
+    for (a, b), (c, d), s in zip(single, grouped, shapes):
+        assert torch.equal(a, c) and torch.equal(b, d), s
+    me._gemm_tn_group(probs[:2])                      # a second, smaller group on the same buffers: accumulate semantics as the single launch
+    me._gemm_tn(*probs[0][:9], dW=single[0][0], db=single[0][1], accumulate=probs[0][11])
+    torch.cuda.synchronize()
+    assert torch.equal(single[0][0], grouped[0][0]) and torch.equal(single[0][1], grouped[0][1])
+
+
 def test_rows_frame_sum_is_exact_and_reproducible():
     """sr_rows_frame_sum (gradient of the per-frame code gather conds[batch_inds], model/Deformer.py:61,75) against float64 sums; ragged,
     empty and unsorted frames, a padded row pitch; two calls give the same bits (torch's index_add -- float atomics -- does not)."""
