@@ -197,8 +197,8 @@ def pooled_mean_weight(count, device):
     `count` local points (SURVEY.md 8(e) caveat B): n_r * R / sum_r n_r, as a device scalar (no host sync)."""
     if not is_distributed():
         return None
-    t = torch.tensor([float(count)], dtype=torch.float32, device=device)
-    tot = t.clone()
+    t = torch.full((1,), float(count), dtype=torch.float32, device=device)     # (a fill, not a host-to-device copy: torch.tensor(..., device=cuda)
+    tot = t.clone()                                                             # does not return before the current stream has drained)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     return (t * dist.get_world_size() / tot.clamp(min=1.0)).squeeze(0)
 

@@ -220,7 +220,7 @@ class LBSkinner(nn.Module):
         rel = self.Js.clone()
         rel[1:] = self.Js[1:] - self.Js[self.parents[1:]]
         local = torch.cat([torch.cat([R, rel.view(1, 24, 3, 1).expand(B, 24, 3, 1)], 3),
-                           torch.tensor([0., 0., 0., 1.], device=poses.device).view(1, 1, 1, 4).expand(B, 24, 1, 4)], 2)
+                           torch.cat([rel.new_zeros(3), rel.new_ones(1)]).view(1, 1, 1, 4).expand(B, 24, 1, 4)], 2)
         G = [None] * 24
         G[0] = local[:, 0]
         for level in self._levels:

@@ -10,13 +10,20 @@ _WCACHE = {}
 
 
 def band_weight_tensor(ws, multires, device):
-    """2*L floats on the device; cached per (weights, device) -- no per-call H2D traffic."""
+    """2*L floats on the device; cached per (weights, device).  A new set of weights (the annealing ratio moves every iteration while it
+    ramps, train.py:158-160) goes up through PINNED memory without blocking: `torch.tensor(values, device=cuda)` copies from pageable
+    memory, and that call does not return before the current stream has drained (measured: 30 ms behind 30 ms of queued GEMMs, 0.01 ms
+    for a pinned non-blocking copy) -- at the first deformer call of an iteration it made the host wait for the whole previous iteration
+    and left the main stream idle until the host had issued again (round 6)."""
     if ws is None:
         ws = (1.0,) * (2 * multires)
     key = (tuple(float(w) for w in ws), str(device))
     t = _WCACHE.get(key)
     if t is None:
-        t = torch.tensor(key[0], dtype=torch.float32, device=device)
+        if len(_WCACHE) > 4096:              # (one entry per distinct ratio: a ramp of thousands of iterations must not grow without bound)
+            _WCACHE.clear()
+        host = torch.tensor(key[0], dtype=torch.float32)
+        t = host.pin_memory().to(device, non_blocking=True) if torch.device(device).type == "cuda" else host.to(device)
         _WCACHE[key] = t
     return t, key[0]
 
