@@ -587,7 +587,7 @@ def main():
                      "note": "event pairs are recorded in a SECOND pass over the same K steps (ms_per_step_instrumented); the headline pass carries no events",
                      "traffic": None},
     }
-    for name in ("r05_pmc_gemm_nt.json", "r04_pmc_gemm_nt.json", "r03_pmc_gemm_nt.json", "r02_pmc_gemm_nt.json", "r01_pmc_gemm_nt.json"):       # PMC passes cannot run inside this process; latest committed collection
+    for name in ("r06_pmc_gemm_nt.json", "r05_pmc_gemm_nt.json", "r04_pmc_gemm_nt.json", "r03_pmc_gemm_nt.json", "r02_pmc_gemm_nt.json", "r01_pmc_gemm_nt.json"):       # PMC passes cannot run inside this process; latest committed collection
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.isfile(pmc):
             with open(pmc) as fh:
