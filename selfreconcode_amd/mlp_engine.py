@@ -321,7 +321,7 @@ def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_g
     seg = _bias_segments(bs[0], R, group) if bs is not None else None
     # weight gradients of a SMALL sweep (deferred mode, their own stream): collected here and launched as one group after the last layer --
     # each is < 100 workgroups that end before the next starts (26 launches per iteration at 27 TFLOP/s in round 5)
-    grouped = [] if (0 < R < GROUP_TN_BELOW and TN_SIDE_STREAM and not PROFILE.enabled and not DEBUG_TN_DELAY_MS) else None
+    grouped = [] if (0 < R < GROUP_TN_BELOW and TN_SIDE_STREAM and not PROFILE.enabled) else None
     with _lib.on_device(A0.device):
         for l in range(nl - 1, -1, -1):
             L = spec.layers[l]
@@ -380,6 +380,8 @@ def reverse(spec, A0, WTs, acts, Ybar, group, need_input_grad=True, need_param_g
             ready.record(main)                                           # every Zbar of the sweep is final here
             side.wait_event(ready)
             with torch.cuda.stream(side):
+                if DEBUG_TN_DELAY_MS:
+                    _debug_delay(A0.device, DEBUG_TN_DELAY_MS)
                 if len(grouped) == 1:
                     p = grouped[0]
                     _gemm_tn(*p[:9], dW=p[9], db=p[10], accumulate=p[11])
