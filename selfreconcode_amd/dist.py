@@ -186,7 +186,8 @@ def assert_same_across_ranks(value, what):
     if not is_distributed():
         return
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    t = torch.tensor([value, -value], dtype=torch.int64, device=dev)
+    t = torch.full((2,), int(value), dtype=torch.int64, device=dev)      # (fills, not a blocking host-to-device copy)
+    t[1].neg_()
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if int(t[0]) != -int(t[1]):
         raise RuntimeError(f"{what} differs between ranks (min {-int(t[1])}, max {int(t[0])}): replicas have diverged")
