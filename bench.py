@@ -575,7 +575,7 @@ def main():
         "loose1080": loose_rec,
         "sdf_mlp_gsamples_per_s": round(sdf_gs, 5),
         "hbm": hbm,
-        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel / mlp_chain_kernel (fp32 MFMA 32x32x2 layer GEMM tile code with fused epilogue; the chain kernel runs all layers of the refiner's two networks in one launch on the device-side live-ray count), EVERY launch of the timed region with >= 128 rows and > 32 columns and every chain launch; "
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel / mlp_layer_pair_kernel (fp32 MFMA 32x32x2 layer GEMM tile code with fused epilogue; the layer-pair kernel runs one layer of the refiner's two networks per launch on the device-side live-ray count), EVERY launch of the timed region with >= 128 rows and > 32 columns and every chain launch; "
                                                 "launches issued while two streams feed the GPU are included (their event intervals can contain the other stream's kernels, "
                                                 "which only lowers the figure); `achieved_alone` restricts to the launches that had the GPU to themselves",
                      "achieved": prof.get("tflops_all", 0.0), "peak": 157.3, "unit": "TFLOP/s", "frac": round(prof.get("tflops_all", 0.0) / 157.3, 4),
