@@ -164,3 +164,37 @@ def test_four_ranks_ragged_shards_and_the_count_guard():
     for rank, g, tv in res:
         torch.testing.assert_close(torch.from_numpy(g), want)
         torch.testing.assert_close(torch.from_numpy(tv), torch.full((5, 3), (0 + 1 + 2 + 0) / 4.0))
+
+
+def _forced_worker(port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SR_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SR_DIST_FORCE_INIT"):
+        os.environ.pop(k, None)
+    from selfreconcode_amd import dist as srdist
+    assert not srdist.is_distributed()
+    assert srdist.pooled_mean_weight(7, torch.device("cpu")) is None            # no group: the pooled-mean weight is not applied at all
+    srdist.force_collectives(True, "cpu")                                       # bench.py's strong_scaling_model: every collective live at world size 1
+    assert srdist.is_distributed() and dist.get_world_size() == 1
+    w = srdist.pooled_mean_weight(7, torch.device("cpu"))
+    p = torch.nn.Parameter(torch.arange(6.).view(2, 3)); p.grad = torch.ones(2, 3) * 3
+    q = torch.nn.Parameter(torch.zeros(4))                                      # no gradient on this rank
+    b = srdist.GradBucket([p, q], early=[q])
+    b.start_early(); b.all_reduce_mean()
+    tv = torch.full((5, 3), 2.0); srdist.all_reduce_mean_(tv)
+    srdist.assert_same_across_ranks(1234, "a count")
+    srdist.force_collectives(False)
+    ok = (not srdist.is_distributed()) and float(w) == 1.0 and torch.equal(p.grad, torch.ones(2, 3) * 3) and torch.equal(q.grad, torch.zeros(4)) and bool((tv == 2.0).all())
+    srdist.force_collectives(True, "cpu")                                       # switching on again reuses the group
+    ok = ok and srdist.is_distributed()
+    out.put(ok)
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_at_world_size_one():
+    """dist.force_collectives (bench.py's `ms_one_rank_of_8_collectives_live_world1`): a one-rank group through the real backend (gloo here,
+    RCCL in the bench), every collective of the step runs and is the identity; switching off leaves the group alive."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(_free_port(), out))
+    p.start(); p.join(120)
+    assert p.exitcode == 0 and out.get(timeout=5) is True
