@@ -442,6 +442,8 @@ int sr_deformed_normals(const float* J, const float* onx, int64_t n, float* out,
  * numerator / denominator sums the backward reads back as `saved`.  partial: [sr_step_reduce_blocks(rows), SR_STEP_LOSS_SLOTS - 1]
  * scratch, may be NULL when that is 1.  gloss: device scalar (cotangent of the loss).
  *   colour (model/network.py:611-618): rays (b, r, c) [P] into gt [N,H,W,3]; mean over frames of the per-frame mean of |gt - colour|_1.
+ *     A row with b[i] < 0 is MASKED in the colour and the normal reduction: no term, no count, exact-zero gradients (the reference
+ *     drops the rays its refiner rejected by a boolean gather, network.py:599-606 -- a host round trip; the mask keeps the shape static).
  *   normal (model/network.py:620-639): gt normal image [N,H,W,3] -> flip diag(-1,1,-1) -> world (R [3,3]) -> unit (valid when
  *     |.| > 1e-4) -> canonical (J^T), against normalize(nx_raw); weighted != 0 multiplies by clamp(-rays . n_def, 0, 1)^2 with
  *     n_def = sr_deformed_normals(J, nx_raw) (detached); masked scatter-mean over frames.  _bwd: gnx_raw [P,3], gJ [P,9] (NULL: skipped).

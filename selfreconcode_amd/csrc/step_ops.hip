@@ -334,6 +334,7 @@ __global__ __launch_bounds__(1024) void color_loss_fwd_kernel(sr_ray_pixels px, 
                                                                float* __restrict__ partial, float* __restrict__ out) {
   reduce_rows(px.P, 0, px.N, partial, out, [&](int64_t i, int& f, float& num, float& den) {
     f = (int)px.b[i];
+    if (f < 0) return;                    // a masked row (frame index -1: a ray the refiner did not accept): no term, no count
     const float* g = gt + (((int64_t)f * px.H + px.r[i]) * px.W + px.c[i]) * 3;
     num = fabsf(g[0] - colors[i * 3]) + fabsf(g[1] - colors[i * 3 + 1]) + fabsf(g[2] - colors[i * 3 + 2]);
     den = 1.f;
@@ -345,6 +346,10 @@ __global__ __launch_bounds__(kBlk) void color_loss_bwd_kernel(sr_ray_pixels px, 
   const float g0 = gloss[0] / (float)px.N;
   for (int64_t i = (int64_t)blockIdx.x * kBlk + threadIdx.x; i < px.P; i += (int64_t)gridDim.x * kBlk) {
     const int f = (int)px.b[i];
+    if (f < 0) {                          // masked row: exact zeros
+      gcolors[i * 3] = 0.f; gcolors[i * 3 + 1] = 0.f; gcolors[i * 3 + 2] = 0.f;
+      continue;
+    }
     const float* g = gt + (((int64_t)f * px.H + px.r[i]) * px.W + px.c[i]) * 3;
     const float s = g0 / fmaxf(saved[1 + kRedMaxFrames + f], 1.f);
 #pragma unroll
@@ -366,6 +371,12 @@ __device__ __forceinline__ NormalRow normal_row(const sr_ray_pixels& px, int64_t
                                                  int weighted) {
   NormalRow o;
   const int f = (int)px.b[i];
+  if (f < 0) {                            // masked row (frame index -1): takes no part, receives exact zeros
+    o.valid = false; o.nlen = 1.f; o.elen = 0.f; o.w = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o.gtn[k] = 0.f; o.nx[k] = 0.f; o.e[k] = 0.f; }
+    return o;
+  }
   const float* g = gtimg + (((int64_t)f * px.H + px.r[i]) * px.W + px.c[i]) * 3;
   const float gc[3] = {-g[0], g[1], -g[2]};                       // the flip (network.py:626)
   float gw[3];

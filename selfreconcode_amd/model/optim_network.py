@@ -97,6 +97,8 @@ class OptimNetwork(nn.Module):
         self.dataset = None
         self.dctnull = None
         self._ray_ctx = None                  # an open ray branch (EAGER_RAY_BRANCH): closed by propagateTmpPsGrad / the next forward
+        self.masked_ray_branch_below = 0      # > 0: with at most this many selected rays the ray branch runs on all of them, masked (see forward())
+        self.ray_valid = None
         self.next_conf = None                 # set by utils.checkpoint.set_hierarchical_config: the stage switch takes effect at the
         self.next_train_conf = None           # next scheduled remesh (update_hierarchical_config, network.py:172-205,464)
 
@@ -651,11 +653,19 @@ class OptimNetwork(nn.Module):
         # one host sync for all the gathers below -- taken on the side stream, which waits for the refiner only: the eikonal /
         # def-regu / DCT work queued above keeps the GPU busy while the host learns the count and issues the next branch
         self._mark('dct issued')
+        # MASKED ray branch (round 6, `masked_ray_branch_below`, off by default): with few selected rays -- one frame per rank: 2048 -- the
+        # colour / normal terms and the implicit-gradient pass run on ALL selected rays, the rays the refiner did not accept carrying a
+        # frame index of -1 into the two loss reductions (no term, no count, exact-zero gradients; a zero row of dl/dTmpPs gives zero
+        # cotangents in the implicit solve).  The second host round trip of the iteration -- the converged-ray count, a wait for the whole
+        # refiner chain -- disappears; every launch of the branch is a single round of workgroups at 300 rows as at 2048, so the GPU does
+        # not notice.  Same terms, same gradients up to the order of the sums (tests/test_training_step_gpu.py).
+        masked = (0 < nr <= self.masked_ray_branch_below and torch.is_grad_enabled() and step_ops.ENABLED
+                  and step_ops.frames_supported(N) and check.is_cuda)
         with torch.cuda.stream(side):
             side.wait_event(refined)
-            conv_idx = hostsync.nonzero(check).view(-1)
+            conv_idx = None if masked else hostsync.nonzero(check).view(-1)
         self._mark('converged rays known')
-        nconv = conv_idx.numel()
+        nconv = nr if masked else conv_idx.numel()
         # The ray branch (see EAGER_RAY_BRANCH): on the side stream -- which is idle from here on -- when the weight-gradient launches
         # have their own ordered stream (deferred mode); otherwise on the main stream, same program order.
         eager = EAGER_RAY_BRANCH and torch.is_grad_enabled() and nconv > 0
@@ -663,7 +673,8 @@ class OptimNetwork(nn.Module):
         rb = side if on_rb_side else main
         if not on_rb_side:
             main.wait_stream(side)
-            conv_idx.record_stream(main)
+            if conv_idx is not None:
+                conv_idx.record_stream(main)
         if nconv > 0:
             ctx = None
             if eager:
@@ -685,11 +696,19 @@ class OptimNetwork(nn.Module):
                             t.record_stream(rb)
                 else:
                     r_poses, r_trans, r_dcond, r_rendcond, r_cameras = poses, trans, d_cond, rendcond, cameras
-                self.TmpPs = initTmpPs[conv_idx]
-                self.TmpPs.requires_grad = True
-                self.batch_inds, self.col_inds, self.row_inds = batch_inds[conv_idx], col_inds[conv_idx], row_inds[conv_idx]
-                # (the rays of the converged pixels from the branch's own camera object: the same rows as rays[conv_idx], bit for bit)
-                self.rays = r_cameras.view_rays(pixels[conv_idx]) if (eager and cam_learn) else rays[conv_idx]
+                if masked:
+                    self.TmpPs = initTmpPs.detach().clone()
+                    self.TmpPs.requires_grad = True
+                    self.batch_inds, self.col_inds, self.row_inds = batch_inds, col_inds, row_inds
+                    self.ray_valid = check
+                    self.rays = r_cameras.view_rays(pixels) if (eager and cam_learn) else rays
+                else:
+                    self.TmpPs = initTmpPs[conv_idx]
+                    self.TmpPs.requires_grad = True
+                    self.batch_inds, self.col_inds, self.row_inds = batch_inds[conv_idx], col_inds[conv_idx], row_inds[conv_idx]
+                    self.ray_valid = None
+                    # (the rays of the converged pixels from the branch's own camera object: the same rows as rays[conv_idx], bit for bit)
+                    self.rays = r_cameras.view_rays(pixels[conv_idx]) if (eager and cam_learn) else rays[conv_idx]
                 extra = self.loss_color_normal(datas, gtCs, r_cameras, [r_dcond, [r_poses, r_trans]], r_rendcond, ratio, N)
                 if on_rb_side and torch.is_tensor(extra):
                     known = torch.cuda.Event()           # the VALUE of the two terms joins the returned loss on the main stream; the forward
@@ -791,6 +810,9 @@ class OptimNetwork(nn.Module):
         device = self.TmpPs.device
         total = 0.
         fused = step_ops.frames_supported(N) and self.TmpPs.is_cuda
+        valid = getattr(self, 'ray_valid', None)
+        # masked branch: the two loss reductions skip rows whose frame index is -1 (csrc/step_ops.hip)
+        b_loss = self.batch_inds if valid is None else torch.where(valid, self.batch_inds, torch.full_like(self.batch_inds, -1))
         sdfs = self.sdf(self.TmpPs, ratio)
         with mlp_engine.input_grads_only():
             nx = torch.autograd.grad(sdfs, self.TmpPs, torch.ones_like(sdfs), retain_graph=True, create_graph=True)[0]
@@ -804,10 +826,16 @@ class OptimNetwork(nn.Module):
             colors = U.compute_netRender_color(self.netRender, self.TmpPs, defVs, nx, crays, self.sdf.rendcond,
                                                None if rendcond is None else rendcond[self.batch_inds], ratio)
             if fused:
-                color_loss = step_ops.ColorLoss.apply(colors, gtCs, self.batch_inds, self.row_inds, self.col_inds)
+                color_loss = step_ops.ColorLoss.apply(colors, gtCs, b_loss, self.row_inds, self.col_inds)
             else:
                 color_loss = (gtCs[self.batch_inds, self.row_inds, self.col_inds, :] - colors).abs().sum(1)
-                color_loss = scatter_mean(color_loss, self.batch_inds, N).mean()
+                if valid is None:
+                    color_loss = scatter_mean(color_loss, self.batch_inds, N).mean()
+                else:
+                    zero_ = torch.zeros((), dtype=color_loss.dtype, device=device)
+                    s_ = torch.zeros(N, dtype=color_loss.dtype, device=device).index_add(0, self.batch_inds, torch.where(valid, color_loss, zero_))
+                    c_ = torch.zeros(N, dtype=color_loss.dtype, device=device).index_add(0, self.batch_inds, valid.to(color_loss.dtype))
+                    color_loss = (s_ / c_.clamp(min=1)).mean()
             self.info['color_loss'] = color_loss.detach()
             total = total + self.conf.get_float('color_weight') * color_loss
         if 'normal' in datas and 'normal_weight' in self.conf and self.conf.get_float('normal_weight') > 0.:
@@ -816,7 +844,7 @@ class OptimNetwork(nn.Module):
                 # gather of the ground-truth normals, flip, rotation into world space, J^T, the |.| of the difference to the unit SDF
                 # gradient, the detached weights clamp(-v . n_deformed, 0, 1)^2 and the masked scatter-mean: one kernel each way
                 normal_loss = step_ops.NormalLoss.apply(nx_raw, jac['J'], datas['normal'].to(device), cameras.R[0], self.rays, weighted,
-                                                        self.batch_inds, self.row_inds, self.col_inds)
+                                                        b_loss, self.row_inds, self.col_inds)
             else:
                 if weighted:
                     cnx, _ = U.compute_deformed_normals(self.sdf, self.deformer, self.TmpPs, defconds, self.batch_inds, ratio, 'test', cache=jac, onx=nx_raw)
@@ -830,6 +858,8 @@ class OptimNetwork(nn.Module):
                 gtnormals = gtnormals.view(-1, 3) @ (cameras.R[0] @ flip).t()
                 gtnorms = gtnormals.norm(dim=1, keepdim=True)
                 valid_mask = (gtnorms > 0.0001)[..., 0]
+                if valid is not None:
+                    valid_mask = valid_mask & valid
                 gtnormals = torch.where(valid_mask[:, None], gtnormals / gtnorms.clamp(min=1e-12), gtnormals)
                 grad_d_p = jac['J']
                 gtnormals = U.small_matvec(grad_d_p.transpose(-2, -1), gtnormals.view(-1, 3))

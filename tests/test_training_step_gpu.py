@@ -214,6 +214,52 @@ def test_deferred_gradients_equal_plain_autograd_over_a_full_iteration():
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6 * max(1.0, float(b.abs().max())))
 
 
+@pytest.mark.parametrize("deferred", [True, False])
+def test_masked_ray_branch_equals_the_compacted_one(deferred):
+    """`OptimNetwork.masked_ray_branch_below` (round 6): the colour / normal terms and the implicit-gradient pass on ALL selected rays with the
+    rays the refiner rejected masked out (frame index -1 in the two loss reductions) against the branch on the compacted list of accepted
+    rays, which costs the iteration its second host round trip.  Same loss terms, same gradients of every network parameter, per-frame
+    tensor and camera parameter, up to the order of the sums; one round trip instead of two."""
+    from selfreconcode_amd import mlp_engine, hostsync
+    from selfreconcode_amd.synthetic import build_synthetic_scene
+    ratio = {'sdfRatio': 1., 'deformerRatio': 0.5, 'renderRatio': 1.}
+    res, trips = [], []
+    for masked in (False, True):
+        mlp_engine.set_deferred_param_grads(deferred)
+        try:
+            net, ds, conf = build_synthetic_scene(device=DEV, frame_num=40, H=128, W=128, resolutions=[(15, 21, 9), (29, 41, 17), (57, 81, 33)],
+                                                  lbs_volume_shape=(17, 57, 33))
+            net.masked_ray_branch_below = 1 << 20 if masked else 0
+            fids = torch.tensor([3, 11, 20], device=DEV)
+            torch.manual_seed(5)
+            seen = []
+            hostsync.TRACE = seen.append
+            try:
+                loss = net(ds.batch(fids), 512, ratio, fids)
+            finally:
+                hostsync.TRACE = None
+            trips.append(seen.count('count on the host'))
+            loss.backward()
+            net.propagateTmpPsGrad(fids, ratio)
+            nrays, nconv = int(net.info['rayInfo'][0]), int(net.info['rayInfo'][1])
+            assert 0 < nconv < nrays                                    # the mask has something to do
+            assert net.TmpPs.shape[0] == (nrays if masked else nconv)
+            if masked:
+                assert torch.equal(net.TmpPs.grad[~net.ray_valid], torch.zeros_like(net.TmpPs.grad[~net.ray_valid]))      # exact zeros on the rejected rays
+            res.append((float(loss), {k: float(v) for k, v in net.info.items() if torch.is_tensor(v) and v.numel() == 1},
+                        [p.grad.clone() for p in net.parameters() if p.requires_grad and p.grad is not None], [t.grad.clone() for t in ds.learnable_weights() if t.grad is not None]))
+        finally:
+            mlp_engine.set_deferred_param_grads(False)
+    assert trips == [2, 1], trips
+    (la, ia, ga, da), (lb, ib, gb, db) = res
+    assert abs(la - lb) < 2e-6 * max(1.0, abs(la)), (la, lb)
+    for k in ia:
+        assert abs(ia[k] - ib[k]) < 1e-5 * max(1.0, abs(ia[k])), (k, ia[k], ib[k])
+    assert len(ga) == len(gb) > 50 and len(da) == len(db) > 3
+    for a, b in zip(ga + da, gb + db):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-6 * max(1.0, float(b.abs().max())))
+
+
 def test_camera_parameters_receive_gradients_when_learnable():
     """opt_camera (config.conf:12-17): focal length / principal point / T / quaternion learnable -> both the loss graph and
     propagateTmpPsGrad's v- and c-terms (network.py:798-813) must reach them."""

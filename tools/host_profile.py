@@ -18,6 +18,7 @@ if os.environ.get('SR_HP_BIND', '0') != '0':                  # the placement be
     from selfreconcode_amd import affinity
     print('host threads:', affinity.bind(0, slot=int(os.environ['SR_HP_SLOT']) if 'SR_HP_SLOT' in os.environ else None))
 net, ds, conf = build_synthetic_scene(device=dev, frame_num=64, stage=os.environ.get('SR_HP_STAGE', 'coarse'), consistent_masks=False)
+net.masked_ray_branch_below = int(os.environ.get('SR_HP_MASK', '0'))        # OptimNetwork.masked_ray_branch_below (bench.py's default: 4096)
 params = [p for p in net.parameters() if p.requires_grad]
 mlp_engine.set_deferred_param_grads(True)
 opt = FusedAdam([{'params': ds.learnable_weights()}, {'params': params}], lr=float(os.environ.get('SR_HP_LR', '1e-4')))
