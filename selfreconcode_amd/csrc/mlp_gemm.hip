@@ -16,6 +16,8 @@
 // makes the ds_read_b128 fragment reads bank-conflict free -- double buffered in LDS plus one
 // register stage: tile t+2 is in flight from global memory while tile t+1 sits in the other LDS
 // buffer and tile t feeds the MFMAs; the one barrier per tile sits in the middle of the MFMA stream.
+// Operand tiles of the K % 32 == 0 layers are fetched with buffer loads (descriptor base + constant
+// lane offset + scalar step offset): the tile loop holds MFMAs and memory instructions only.
 #include "sr_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -455,7 +457,10 @@ template <int WM, int WN, int TM, int TN, bool KTAIL>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_kernel(sr_gemm_args g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // (Tried in round 3: delaying the second workgroup of every CU by 0.1 - 0.6 of a tile at the start of a launch, so that the two
-  // co-resident workgroups do not run their prologues / epilogues in phase -- no effect, 119.0 +- 0.4 TFLOP/s at every delay.)
+  // co-resident workgroups do not run their prologues / epilogues in phase -- no effect, 119.0 +- 0.4 TFLOP/s at every delay.  Round 6's
+  // cycle stamps (tools/nt_lab.hip, profiles/r06_nt_lab.md) show why: the two workgroups of a CU ALTERNATE by themselves -- the younger
+  // one is starved in its prologue until the older one's tile loop ends -- so a CU completes a tile per (tile loop alone), and what that
+  // loop costs beyond its MFMAs is the issue time of its other instructions: hence the buffer loads of TileLoader::load_full.)
   gemm_nt_tile<WM, WN, TM, TN, KTAIL>(g, blockIdx.x, smem);
 }
 
