@@ -265,12 +265,15 @@ int sr_newton_apply(const sr_newton2_args* host_args, void* stream);
  * The whole of utils/FindSurfacePs.py::OptimizeSurfacePs (:114-163) for P rays as a fixed sequence of launches whose row
  * count lives in device memory: `live[k]` = unfinished rays entering phase k (live[0] = P).  The queue of unfinished rays
  * (x, v, frame, orig: two copies, phase parity selects) is compacted by wave ballots at the end of every phase, so finished
- * rays leave the layer GEMMs immediately and the host never learns a count.  Per phase the caller issues
- *   sr_refine_embed -> sr_mlp_chain(forward, m_dev = live + k) -> sr_refine_mid
+ * rays leave the layer GEMMs immediately and the host never learns a count.  After sr_refine_init the caller issues per phase
+ *   sr_mlp_chain(forward, m_dev = live + k) -> sr_refine_mid
  *   [-> sr_mlp_chain(reverse) -> sr_refine_finish   for the update phases 1..times]
+ * The kernels that put rays into a queue (_init: phase 0; _mid mode 0: phase 1; _finish of phase k: phase k + 1) also write those
+ * rays' first-layer input rows a0 / a0d when both pointers are given; sr_refine_embed(phase) writes the same rows for the queue
+ * of `phase` as a launch of its own (same arithmetic, same bits; needed only by a caller that passes a0 = a0d = NULL to the others).
  * phase 0 (mid mode 0): initial test; phases 1..times (mode 1): test of the current points + Newton update of the failing
  * ones; phase times+1 (mode 2): test of the last update.  p_out / conv_out are indexed by the rays' original position.
- * The layer chains read a0 / a0d (first-layer inputs, written by _embed) and leave f in sdf_out[:,0], the deformation
+ * The layer chains read a0 / a0d (first-layer inputs) and leave f in sdf_out[:,0], the deformation
  * offset in def_out[:,0:3]; the reverse chains start from `unit` rows (1,0,0,0) (SDF) and `t` rows (deformer) and leave
  * the input cotangents in a0bar (+ skipbar: the skip-concat part, n_skip columns) and a0dbar. */
 typedef struct {

@@ -6,13 +6,16 @@
 // visits the host, the layer chains (sr_mlp_chain) and the kernels below read it from the `live` array.
 //
 // Phases of one call (P rays, T = times):
-//   phase 0      : embed -> forward chain -> mid(CHECK): rays that already pass are retired, the rest compacted
-//   phase 1..T   : embed -> forward chain -> mid(STEP): LBS + Jacobian, convergence test of the current points,
+//   phase 0      : forward chain -> mid(CHECK): rays that already pass are retired, the rest compacted
+//   phase 1..T   : forward chain -> mid(STEP): LBS + Jacobian, convergence test of the current points,
 //                  cotangents of the residual -> reverse chain -> finish: Newton update of the failing rays,
 //                  retirement of the passing ones, compaction
-//   phase T+1    : embed -> forward chain -> mid(FINAL): test of the last update, everything retired
-// = 3 + 5 T + 3 launches, whatever the number of live rays.  Results land at the rays' ORIGINAL indices, so the order in
-// which the waves claim queue slots does not matter (a row's arithmetic does not depend on its position).
+//   phase T+1    : forward chain -> mid(FINAL): test of the last update, everything retired
+// = 1 + 2 + 4 T + 2 launches, whatever the number of live rays.  Every kernel that puts a ray into a queue (init, mid(CHECK),
+// finish) also writes the ray's first-layer input rows of both networks at its slot (embed_rows below), so the next forward
+// chain follows it directly; sr_refine_embed is the same arithmetic as a launch of its own.  Results land at the rays' ORIGINAL
+// indices, so the order in which the waves claim queue slots does not matter (a row's arithmetic does not depend on its position).
+#include <algorithm>
 #include "lbs_device.h"
 
 namespace {
@@ -27,6 +30,27 @@ __device__ __forceinline__ int wave_compact_slot(bool keep, int32_t* counter) {
   return base + (int)__popcll(m & ((1ull << lane) - 1ull));
 }
 
+// One element of a ray's first-layer input rows, columns [0, ld_a0) = SDF network [x | PE_L(x)], [ld_a0, ld_a0 + ld_a0d) =
+// deformer [x | PE_L(x) | code[frame]]; same arithmetic as pe_embed_kernel (model/Embedder.py:9-41).
+__device__ __forceinline__ void embed_store(const sr_refine_args& g, int64_t p, int c, float x0, float x1, float x2, int frame) {
+  const bool def = c >= g.ld_a0;
+  if (def) c -= g.ld_a0;
+  const int L = def ? g.L_def : g.L_sdf;
+  const float* w = def ? g.w_def : g.w_sdf;
+  float v = 0.f;
+  if (c < 3) {
+    v = c == 0 ? x0 : (c == 1 ? x1 : x2);
+  } else if (c < 3 + 6 * L) {
+    const int k = (c - 3) / 6, r = (c - 3) % 6, comp = r % 3;
+    const float a = (comp == 0 ? x0 : (comp == 1 ? x1 : x2)) * (float)(1 << k);
+    const float wk = w[2 * k + (r >= 3)];
+    v = r < 3 ? wk * sinf(a) : wk * cosf(a);
+  } else if (def && c < 3 + 6 * L + g.E) {
+    v = g.conds[(int64_t)frame * g.ld_conds + (c - 3 - 6 * L)];
+  }
+  (def ? g.a0d + p * g.ld_a0d : g.a0 + p * g.ld_a0)[c] = v;
+}
+
 __global__ __launch_bounds__(256) void refine_init_kernel(sr_refine_args g) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < g.P) {
@@ -37,34 +61,44 @@ __global__ __launch_bounds__(256) void refine_init_kernel(sr_refine_args g) {
     g.unit[i * 4] = 1.f; g.unit[i * 4 + 1] = 0.f; g.unit[i * 4 + 2] = 0.f; g.unit[i * 4 + 3] = 0.f;
   }
   if (i <= g.times + 2) g.live[i] = i == 0 ? g.P : 0;
+  if (g.a0 && g.a0d) {                                  // phase 0's first-layer inputs: every ray, at its own index
+    const int wtot = (int)(g.ld_a0 + g.ld_a0d);
+    const int64_t total = (int64_t)g.P * wtot;
+    for (int64_t e = i; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t p = e / wtot;
+      embed_store(g, p, (int)(e % wtot), g.p0[p * 3], g.p0[p * 3 + 1], g.p0[p * 3 + 2], (int32_t)g.batch_inds[p]);
+    }
+  }
 }
 
-// First-layer inputs of both networks for the live rays of `phase`: [x | PE_L(x)] (SDF) and [x | PE_L(x) | code[frame]]
-// (deformer), same arithmetic as pe_embed_kernel (model/Embedder.py:9-41).
+// First-layer inputs of both networks for the live rays of `phase` (the stand-alone form of what init / mid(CHECK) / finish do
+// for the rays they enqueue).
 __global__ __launch_bounds__(256) void refine_embed_kernel(sr_refine_args g, int phase) {
   const int M = g.live[phase], cur = phase & 1;
-  const int wd = 3 + 6 * g.L_def + g.E;
-  const int64_t total = (int64_t)M * (g.ld_a0 + g.ld_a0d);
+  const int wtot = (int)(g.ld_a0 + g.ld_a0d);
+  const int64_t total = (int64_t)M * wtot;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t p = i / (g.ld_a0 + g.ld_a0d);
-    int c = (int)(i % (g.ld_a0 + g.ld_a0d));
-    const bool def = c >= g.ld_a0;
-    if (def) c -= g.ld_a0;
-    const int L = def ? g.L_def : g.L_sdf;
-    const float* w = def ? g.w_def : g.w_sdf;
-    float v = 0.f;
-    if (c < 3) {
-      v = g.x[cur][p * 3 + c];
-    } else if (c < 3 + 6 * L) {
-      const int k = (c - 3) / 6, r = (c - 3) % 6, comp = r % 3;
-      const float a = g.x[cur][p * 3 + comp] * (float)(1 << k);
-      const float wk = w[2 * k + (r >= 3)];
-      v = r < 3 ? wk * sinf(a) : wk * cosf(a);
-    } else if (def && c < wd) {
-      v = g.conds[(int64_t)g.frame[cur][p] * g.ld_conds + (c - 3 - 6 * L)];
-    }
-    (def ? g.a0d + p * g.ld_a0d : g.a0 + p * g.ld_a0)[c] = v;
+    const int64_t p = i / wtot;
+    embed_store(g, p, (int)(i % wtot), g.x[cur][p * 3], g.x[cur][p * 3 + 1], g.x[cur][p * 3 + 2], g.frame[cur][p]);
   }
+}
+
+// The enqueueing kernels work on kEnq rays per 256-thread workgroup: one ray per lane of the first quarter-wave for the per-ray
+// part, then ALL 256 threads write the kEnq x (ld_a0 + ld_a0d) input elements of the rays that stay in the queue.  (One ray
+// per thread would leave a 6k-ray call with 24 workgroups for ~1.3 M sin / cos evaluations.)
+constexpr int kEnq = 16;
+struct EnqRow { float x0, x1, x2; int frame, slot; };
+__device__ __forceinline__ void embed_rows(const sr_refine_args& g, EnqRow* rows, bool keep, int slot, float x0, float x1, float x2, int frame) {
+  if (threadIdx.x < kEnq) rows[threadIdx.x] = EnqRow{x0, x1, x2, frame, keep ? slot : -1};
+  __syncthreads();
+  if (g.a0 && g.a0d) {
+    const int wtot = (int)(g.ld_a0 + g.ld_a0d);
+    for (int i = threadIdx.x; i < kEnq * wtot; i += blockDim.x) {
+      const EnqRow r = rows[i / wtot];
+      if (r.slot >= 0) embed_store(g, r.slot, i % wtot, r.x0, r.x1, r.x2, r.frame);
+    }
+  }
+  __syncthreads();
 }
 
 struct Residual { float s, ex, ey, ez; bool ok; };
@@ -91,6 +125,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void refine_mid_kernel(sr_refine_args g, int phase) {
   __shared__ float sA[8 * srlbs::NJ * 12];
   __shared__ float sT[8 * 3];
+  __shared__ EnqRow rows[kEnq];
+  constexpr int RPB = MODE == 0 ? kEnq : 256;             // rays per workgroup and pass (CHECK also writes the kept rays' input rows)
   const bool stage = g.nframes <= 8;
   if (stage) {
     for (int i = threadIdx.x; i < g.nframes * srlbs::NJ * 12; i += blockDim.x) sA[i] = g.A[i];
@@ -98,9 +134,9 @@ __global__ __launch_bounds__(256) void refine_mid_kernel(sr_refine_args g, int p
     __syncthreads();
   }
   const int M = g.live[phase], cur = phase & 1, nxt = cur ^ 1;
-  for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < M; base += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t base = (int64_t)blockIdx.x * RPB; base < M; base += (int64_t)gridDim.x * RPB) {
     const int64_t i = base + threadIdx.x;
-    const bool valid = i < M;
+    const bool valid = (int)threadIdx.x < RPB && i < M;
     bool ok = false;
     float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
     int frame = 0;
@@ -143,6 +179,7 @@ __global__ __launch_bounds__(256) void refine_mid_kernel(sr_refine_args g, int p
           g.frame[nxt][slot] = frame;
           g.orig[nxt][slot] = g.orig[cur][i];
         }
+        embed_rows(g, rows, keep, slot, px, py, pz, frame);
       }
     }
   }
@@ -169,11 +206,13 @@ __device__ __forceinline__ void pe_pullback(const float (&x)[3], int L, const fl
 // End of a step: g = w1 sign(f) grad f + w2 (t + J_off^T t),  p <- p - L g / |g|^2 for the rays that failed this step's
 // test (FindSurfacePs.py:146-151); the passing ones are retired at their current position; compaction.
 __global__ __launch_bounds__(256) void refine_finish_kernel(sr_refine_args g, int phase) {
+  __shared__ EnqRow rows[kEnq];
   const int M = g.live[phase], cur = phase & 1, nxt = cur ^ 1;
-  for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < M; base += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t base = (int64_t)blockIdx.x * kEnq; base < M; base += (int64_t)gridDim.x * kEnq) {
     const int64_t i = base + threadIdx.x;
-    const bool valid = i < M;
+    const bool valid = (int)threadIdx.x < kEnq && i < M;
     bool keep = false;
+    int frame = 0;
     float x[3] = {0.f, 0.f, 0.f};
     if (valid) {
 #pragma unroll
@@ -203,9 +242,11 @@ __global__ __launch_bounds__(256) void refine_finish_kernel(sr_refine_args g, in
     if (keep) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) { g.x[nxt][slot * 3 + c] = x[c]; g.v[nxt][slot * 3 + c] = g.v[cur][i * 3 + c]; }
-      g.frame[nxt][slot] = g.frame[cur][i];
+      frame = g.frame[cur][i];
+      g.frame[nxt][slot] = frame;
       g.orig[nxt][slot] = g.orig[cur][i];
     }
+    embed_rows(g, rows, keep, slot, x[0], x[1], x[2], frame);
   }
 }
 
@@ -224,8 +265,12 @@ int sr_refine_init(const sr_refine_args* a, void* stream) {
   const int rc = check_args(a);
   if (rc != SR_OK) return rc;
   if (!a->p0 || !a->rays || !a->batch_inds || !a->unit) { if (a->P > 0) return SR_EINVAL; }
+  if ((a->a0 != nullptr) != (a->a0d != nullptr)) return SR_EINVAL;
+  if (a->a0 && (!a->w_sdf || !a->w_def || (a->E > 0 && !a->conds))) return SR_EINVAL;
   const int64_t n = a->P > a->times + 3 ? a->P : a->times + 3;
-  hipLaunchKernelGGL(refine_init_kernel, dim3((unsigned)sr_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, *a);
+  int64_t blocks = sr_cdiv(n, 256);                                  // one thread per ray (and per `live` entry) ...
+  if (a->a0) blocks = std::max<int64_t>(blocks, sr_stream_grid((int64_t)a->P * (a->ld_a0 + a->ld_a0d), 256));   // ... striding the input elements
+  hipLaunchKernelGGL(refine_init_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
   return sr_launch_status();
 }
 
@@ -242,8 +287,9 @@ int sr_refine_mid(const sr_refine_args* a, int32_t phase, int32_t mode, void* st
   if (rc != SR_OK || a->P == 0) return rc;
   if (phase < 0 || phase > a->times + 1 || mode < 0 || mode > 2 || !a->sdf_out || !a->def_out) return SR_EINVAL;
   if (mode == 1 && (!a->conv || !a->t || !a->s)) return SR_EINVAL;
+  if (mode == 0 && ((a->a0 != nullptr) != (a->a0d != nullptr) || (a->a0 && (!a->w_sdf || !a->w_def || (a->E > 0 && !a->conds))))) return SR_EINVAL;
   const dim3 grid(sr_stream_grid(a->P, 256)), block(256);
-  if (mode == 0) hipLaunchKernelGGL(refine_mid_kernel<0>, grid, block, 0, (hipStream_t)stream, *a, phase);
+  if (mode == 0) hipLaunchKernelGGL(refine_mid_kernel<0>, dim3(sr_stream_grid((int64_t)a->P * (256 / kEnq), 256)), block, 0, (hipStream_t)stream, *a, phase);
   else if (mode == 1) hipLaunchKernelGGL(refine_mid_kernel<1>, grid, block, 0, (hipStream_t)stream, *a, phase);
   else hipLaunchKernelGGL(refine_mid_kernel<2>, grid, block, 0, (hipStream_t)stream, *a, phase);
   return sr_launch_status();
@@ -254,7 +300,8 @@ int sr_refine_finish(const sr_refine_args* a, int32_t phase, void* stream) {
   if (rc != SR_OK || a->P == 0) return rc;
   if (phase < 1 || phase > a->times || !a->conv || !a->t || !a->s || !a->a0bar || !a->a0dbar || !a->sdf_out || !a->w_sdf || !a->w_def) return SR_EINVAL;
   if (a->ld_a0bar < 3 + 6 * a->L_sdf || a->ld_a0dbar < 3 + 6 * a->L_def || (a->skipbar && a->n_skip > a->ld_skipbar)) return SR_EINVAL;
-  hipLaunchKernelGGL(refine_finish_kernel, dim3(sr_stream_grid(a->P, 256)), dim3(256), 0, (hipStream_t)stream, *a, phase);
+  if ((a->a0 != nullptr) != (a->a0d != nullptr) || (a->E > 0 && a->a0 && !a->conds)) return SR_EINVAL;
+  hipLaunchKernelGGL(refine_finish_kernel, dim3(sr_stream_grid((int64_t)a->P * (256 / kEnq), 256)), dim3(256), 0, (hipStream_t)stream, *a, phase);
   return sr_launch_status();
 }
 }

@@ -304,16 +304,19 @@ def _optimize_device_driven(ev, cam, rays, initTmpPs, batch_inds, dthreshold, at
                 e1.record()
                 marks.append((e0, e1, phase, flop_per_row))
 
-        def evaluate(phase):
-            _lib.call("sr_refine_embed", ra, phase, st)
+        def evaluate(phase):                               # the first-layer inputs were written by whoever enqueued the rays
             chain(fwd, phase, fwd_flop)
+        watch = ENQUEUE_WATCH
+        if watch is not None: watch(a, ws, 0, st)
         evaluate(0)
         _lib.call("sr_refine_mid", ra, 0, 0, st)
+        if watch is not None: watch(a, ws, 1, st)
         for k in range(1, times + 1):
             evaluate(k)
             _lib.call("sr_refine_mid", ra, k, 1, st)
             chain(rev, k, rev_flop)
             _lib.call("sr_refine_finish", ra, k, st)
+            if watch is not None: watch(a, ws, k + 1, st)
         evaluate(times + 1)
         _lib.call("sr_refine_mid", ra, times + 1, 2, st)
         if prof is not None:
@@ -323,6 +326,7 @@ def _optimize_device_driven(ev, cam, rays, initTmpPs, batch_inds, dthreshold, at
     return initTmpPs.detach(), conv_out.bool(), ws
 
 
+ENQUEUE_WATCH = None   # tests: called as (args, workspace, phase, stream) after each launch that filled the queue of `phase`
 _PINNED = {}   # device -> pinned int64 scratch for the asynchronous live-ray counts
 COMPACT_BELOW = 0.5   # compact the working set once fewer than this fraction of its rays are still unfinished
 

@@ -152,3 +152,32 @@ def test_refiner_edge_cases():
             outs.append((ps.cpu(), ok.cpu()))
         F.DEVICE_DRIVEN = True
         assert torch.equal(outs[0][1], outs[1][1]) and torch.allclose(outs[0][0], outs[1][0], atol=5e-6)
+
+
+def test_enqueueing_kernels_write_the_rows_the_embed_launch_would():
+    """init, mid(CHECK) and finish write the first-layer input rows of the rays they put into the next queue; the stand-alone
+    sr_refine_embed on the same queue must produce the same bits (padding columns included)."""
+    import ctypes
+    from selfreconcode_amd import _lib
+    from selfreconcode_amd.utils import FindSurfacePs as F
+    sdf, comp = _nets()
+    N, P, times = 3, 3001, 4
+    defconds = [fx.det_tensor((N, 128), 3, 0.1).to(DEV), [fx.det_tensor((N, 24, 3), 1, 0.1).to(DEV), fx.det_tensor((N, 3), 2, 0.05).to(DEV)]]
+    cam, rays, p0, bi, _ = _rays(P, N)
+    seen = []
+
+    def watch(a, ws, phase, st):
+        live = int(ws.live[phase])
+        got = (ws.a0[:live].clone(), ws.a0d[:live].clone())
+        ws.a0.fill_(float('nan')); ws.a0d.fill_(float('nan'))
+        _lib.call("sr_refine_embed", ctypes.byref(a), phase, st)
+        for fused, alone in zip(got, (ws.a0[:live], ws.a0d[:live])):
+            assert torch.isfinite(alone).all() and torch.equal(fused, alone), phase
+        seen.append((phase, live))
+    F.ENQUEUE_WATCH = watch
+    try:
+        F.OptimizeSurfacePs(cam.to(DEV), rays.to(DEV), p0.to(DEV).clone(), bi.to(DEV), sdf, RATIO, comp, defconds, dthreshold=5.e-5, athreshold=0.3,
+                            w1=3.05, w2=1., times=times)
+    finally:
+        F.ENQUEUE_WATCH = None
+    assert [p for p, _ in seen] == list(range(times + 2)) and seen[0][1] == P and seen[1][1] > 0
