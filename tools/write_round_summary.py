@@ -21,7 +21,9 @@ an iteration that make the host wait: the two count round trips), `{tag}_hbm_ker
 `{tag}_nt_lab.md` -- these read 15-20 % below the sustained rates).
 
 Headline (`{tag}_bench.json`): **{d['ms_per_step']:.2f} ms / iteration = {d['value']:.2f} it/s on the coarse stage at lr 1e-4** (round 5: 44.07 on the builder's boxes, 44.79 on the
-driver's); earlier runs of the same command on other boxes this round: 42.51, 42.99; A / B runs: 42.2 - 42.9.  Late rate {d['late_schedule_lr']['ms_per_step']:.2f} ms, fine stage
+driver's); the same tree and command on a second box (`{tag}_bench_second_box.json`, 2332 MHz at 1147 W): 42.72 ms, whole step 0.678; earlier trees of this round on other
+boxes: 42.51, 42.56, 42.99; A / B runs of this tree: 42.2 - 42.7 -- the boxes differ by ~3 %, every kernel of the trace with them;
+**round 5's tree and this one alternating on ONE box (`{tag}_vs_r05_same_box.md`): 43.58 -> 42.63 ms, whole step 0.657 -> 0.683; one rank of 8: 20.03 -> 18.15 ms**.  Late rate {d['late_schedule_lr']['ms_per_step']:.2f} ms, fine stage
 {d['fine_stage']['ms_per_step']:.2f} ms, configs[4] (1080 x 1080, config_loose.conf) {d['loose1080']['ms_per_step']:.2f} ms.  Roofline record: NT tile code {r['achieved']:.1f} TFLOP/s over all
 recorded launches ({r['frac']:.3f} of 157.3; >= 64k rows {r['achieved_launches_ge_64k_rows']:.1f}), weight-gradient kernel {r['weight_gradient_gemm']['achieved']:.1f} ({r['weight_gradient_gemm']['frac']:.3f}; round 5: 0.646),
 **whole step 4.568 TFLOP / {d['ms_per_step']:.2f} ms = {r['whole_step_tflops']:.1f} TFLOP/s ({r['whole_step_frac']:.3f} of the fp32 MFMA peak; round 5: 0.659 builder / 0.648 driver)**.  Clock in the window
